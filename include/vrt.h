@@ -1,0 +1,267 @@
+/*
+ * vrt.h — C ABI of libvrt.so, the MI355X-native tracing core for VisualRayTrace.
+ *
+ * Every entry point here stands in for a tracer-facing call of the Unity C# host
+ * (paths relative to VisualRayTrace/Assets/Scripts/RayTracer/).  The reference has
+ * no native boundary of its own; the seam is the data its host already owns:
+ * camera (RayTracerUnity.cs:285, Info/ViewPortPlaneInformation.cs:86-99), scene
+ * colliders/materials/lights (Tracer/WhittedTracer.cs:43-88,
+ * Util/RayTraceUtility.cs:478-528), settings (RayTracerUnity.cs:102-168), and the
+ * outputs it consumes: Color[] PixelColorData (Info/TextureInformation.cs:36) and
+ * the ray polyline for the LineRenderer (RayTracerUnity.cs:620-654).
+ *
+ * Conventions: all structs are blittable (LayoutKind.Sequential, 4-byte floats and
+ * ints, pointers as IntPtr); Vector3 = 3 floats, Color = 4 floats.  Functions
+ * return 0 or a negative vrt_status and never throw.  Inputs are copied before the
+ * call returns; output buffers are caller-owned and fully written on success.
+ * One call at a time per vrt_ctx.
+ */
+#ifndef VRT_H
+#define VRT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VRT_ABI_VERSION 1
+
+typedef struct vrt_ctx vrt_ctx;
+
+typedef enum vrt_status {
+    VRT_OK = 0,
+    VRT_ERR_INVALID = -1,   /* bad argument (null pointer, size out of range, bad id) */
+    VRT_ERR_NO_DEVICE = -2, /* no HIP device / HIP runtime unavailable */
+    VRT_ERR_HIP = -3,       /* a HIP call failed; see vrt_last_error */
+    VRT_ERR_STATE = -4,     /* scene or camera not set */
+    VRT_ERR_CAPACITY = -5   /* a fixed capacity was exceeded (lights, depth, records) */
+} vrt_status;
+
+/* Material classes; values follow RayTraceUtility.MaterialType
+ * (Util/RayTraceUtility.cs:106).  The class is what DetermineMaterialType
+ * (Util/RayTraceUtility.cs:139-152) derives from the Unity material name. */
+enum { VRT_MAT_SOLID = 1, VRT_MAT_METAL = 2, VRT_MAT_DIELECTRIC = 3 };
+
+/* Light kinds (Util/RayTraceUtility.cs:495-526). */
+enum { VRT_LIGHT_DIRECTIONAL = 0, VRT_LIGHT_POINT = 1 };
+
+/* Sampler ids = AASamplingStrategy (AntiAliasingStrategy.cs:8). */
+enum {
+    VRT_SAMPLER_REGULAR = 0, VRT_SAMPLER_RANDOM = 1, VRT_SAMPLER_JITTERED = 2,
+    VRT_SAMPLER_NROOKS = 3, VRT_SAMPLER_MULTIJITTERED = 4, VRT_SAMPLER_HAMMERSLEY = 5
+};
+
+/* Behaviour switches.  0 reproduces the shipped C# including its quirks; each bit
+ * replaces one quirk by the textbook behaviour. */
+enum {
+    VRT_FIX_PRIMARY_SKY = 1u << 0, /* primary misses return the sky colour instead of black
+                                      (RayTracerUnity.cs:582-592) */
+    VRT_FIX_AO_BASIS = 1u << 1,    /* ambient-occlusion ray always leaves along the normal; the
+                                      reference poisons it with NaN for most normals
+                                      (Light/AmbientOccluder.cs:66-73) */
+    VRT_FIX_DIELECTRIC = 1u << 2   /* Fresnel reflection + refraction with EtaIn/EtaOut instead
+                                      of the always-total-internal-reflection wiring
+                                      (Material/DielectricMaterial.cs:73, BTDF/FresnelTransmitterBTDF.cs:57-69) */
+};
+
+/* Kernel organisation. */
+enum {
+    VRT_MODE_AUTO = 0,
+    VRT_MODE_MEGAKERNEL = 1, /* one lane follows one pixel through all samples and bounces */
+    VRT_MODE_WAVEFRONT = 2   /* per-bounce kernels over compacted SoA ray queues in HBM */
+};
+
+/* Ray classes, used for counters and path records.  One ray = one intersection query
+ * (a Physics.Raycast call site).  PRECHECK is the any-hit test of
+ * RayTracerUnity.cs:582, answered by the primary closest-hit query. */
+enum {
+    VRT_RAY_PRECHECK = 0, VRT_RAY_PRIMARY = 1, VRT_RAY_REFLECT = 2,
+    VRT_RAY_TRANSMIT = 3, VRT_RAY_SHADOW = 4, VRT_RAY_AO = 5, VRT_RAY_CLASSES = 6
+};
+
+/* SphereCollider in world space. */
+typedef struct vrt_sphere {
+    float center[3];
+    float radius;
+    int32_t material; /* index into vrt_scene_desc.materials */
+} vrt_sphere;
+
+/* BoxCollider in world space: centre, three orthonormal axes (rows) and half extents. */
+typedef struct vrt_box {
+    float center[3];
+    float axis[9];
+    float half[3];
+    int32_t material;
+} vrt_box;
+
+/* MeshRenderer.material as the tracer reads it (Tracer/WhittedTracer.cs:49-86). */
+typedef struct vrt_material {
+    int32_t type;   /* VRT_MAT_* */
+    float color[4]; /* mat.color, passed to SetCD */
+} vrt_material;
+
+/* A scene light (Light/PointLight.cs, Light/DirectionalLight.cs). */
+typedef struct vrt_light {
+    int32_t type;         /* VRT_LIGHT_* */
+    float vec[3];         /* point: position; directional: the vector GetDirection returns */
+    float ls;             /* radiance factor (Light.intensity) */
+    float color[4];
+    int32_t cast_shadows; /* AbstractLight.CastShadows */
+    float location[3];    /* directional only: _location used by its InShadow (never assigned
+                             in the reference, so zero) */
+} vrt_light;
+
+/* Constants of the three singleton materials and the ambient occluder
+ * (Util/RayTraceUtility.cs:15-76,481-490).  vrt_shading_defaults fills in the shipped values. */
+typedef struct vrt_shading {
+    float solid_ka, solid_kd, solid_ks, solid_exp;
+    float metal_ka, metal_kd, metal_ks, metal_exp, metal_kr;
+    float metal_cr[4];
+    float glass_ka, glass_kd, glass_ks, glass_exp;
+    float glass_eta_in, glass_eta_out; /* used only with VRT_FIX_DIELECTRIC */
+    float ao_min_amount[4];
+    float ao_ls;
+    float ao_color[4];
+} vrt_shading;
+
+typedef struct vrt_scene_desc {
+    uint32_t n_spheres;
+    const vrt_sphere* spheres;
+    uint32_t n_boxes;
+    const vrt_box* boxes;
+    /* MeshColliders flattened to one indexed triangle list; single-sided, front face =
+     * clockwise winding seen from outside (Unity convention), flat normals. */
+    uint32_t n_vertices;
+    const float* vertices;        /* n_vertices * 3 */
+    uint32_t n_triangles;
+    const uint32_t* indices;      /* n_triangles * 3 */
+    const int32_t* tri_material;  /* n_triangles, or NULL for material 0 */
+    uint32_t n_materials;
+    const vrt_material* materials;
+    uint32_t n_lights;
+    const vrt_light* lights;      /* at most VRT_MAX_LIGHTS */
+    vrt_shading shading;
+} vrt_scene_desc;
+
+#define VRT_MAX_LIGHTS 8
+#define VRT_MAX_DEPTH 15
+
+/* Primitive ids reported by the library: spheres first, then boxes, then triangles,
+ * each in the order given; -1 = miss. */
+
+/* Camera: rayOrigin, PlaneBorderPoints[0], PlaneXAxis, PlaneYAxis
+ * (RayTracerUnity.cs:285,486-517).  width = pixels along X, height = pixels along Y;
+ * the reference is square (TextureDimension). */
+typedef struct vrt_camera {
+    float origin[3];
+    float p0[3];
+    float x_axis[3];
+    float y_axis[3];
+    int32_t width;
+    int32_t height;
+} vrt_camera;
+
+/* One recorded ray of the ray tree of a pixel (feeds RT_rec_points /
+ * LineRenderer, RayTracerUnity.cs:620-654). */
+typedef struct vrt_path_seg {
+    float origin[3];
+    float end[3];      /* hit point, or origin + direction * range on a miss */
+    int32_t kind;      /* VRT_RAY_* (never PRECHECK) */
+    int32_t depth;     /* recursion depth of the TraceRay call that cast it */
+    int32_t hit_prim;  /* primitive id or -1 */
+    int32_t sample;    /* anti-aliasing sample index */
+} vrt_path_seg;
+
+typedef struct vrt_params {
+    int32_t spp;          /* SampleSize */
+    int32_t n_sets;       /* SampleSetCount; rows of `offsets` */
+    const float* offsets; /* n_sets * spp (x,y) pairs in access order, i.e.
+                             samples[jump + shuffled[jump + i]] (Sampler/AbstractSampler.cs:163);
+                             NULL = all zero */
+    uint32_t seed;        /* selects the set per pixel: set = vrt_pixel_set(seed, pixel, n_sets) */
+    int32_t max_depth;    /* GlobalWorld.MaxDepth */
+    float range;          /* RayTrace_Range */
+    uint32_t flags;       /* VRT_FIX_* */
+    int32_t mode;         /* VRT_MODE_* */
+    /* Tile sharding: the frame is cut into strips of tile_rows rows; this call renders
+     * strips s with s % tile_count == tile_index and leaves the other rows untouched. */
+    int32_t tile_index;
+    int32_t tile_count;   /* <= 1: whole frame */
+    int32_t tile_rows;
+    /* Path recording for a bounded set of pixels (linear index h*width+v). */
+    int32_t n_record_pixels;
+    const int32_t* record_pixels;
+    int32_t record_cap;           /* segments per recorded pixel */
+    vrt_path_seg* record_out;     /* n_record_pixels * record_cap, host memory */
+    int32_t* record_count_out;    /* n_record_pixels: segments produced (may exceed cap;
+                                     only the first cap are stored) */
+} vrt_params;
+
+typedef struct vrt_stats {
+    uint64_t rays[VRT_RAY_CLASSES]; /* intersection queries per class */
+    uint64_t pixels;                /* pixels rendered by this call */
+    float gpu_ms;                   /* device time of the render kernels (HIP events) */
+    float bvh_build_ms;             /* device time of the last LBVH build (vrt_set_scene) */
+    uint32_t bvh_nodes;
+    int32_t mode_used;              /* VRT_MODE_* actually run */
+} vrt_stats;
+
+/* Lifetime.  Replaces RayTracerUnity.Start (RayTracerUnity.cs:266-307), which builds the
+ * world and tracer objects.  device = HIP device ordinal. */
+int vrt_create(int device, vrt_ctx** out);
+int vrt_destroy(vrt_ctx* ctx);
+const char* vrt_last_error(vrt_ctx* ctx);
+
+/* Fills the shipped constants (Util/RayTraceUtility.cs:43-47,73-76,484-489,
+ * BRDF/LambertianBRDF.cs:19, BRDF/GlossySpecularBRDF.cs:17-20). */
+void vrt_shading_defaults(vrt_shading* out);
+void vrt_params_defaults(vrt_params* out);
+
+/* Scene upload; builds the LBVH on the device when the primitive count calls for it.
+ * Replaces the WorldInformation constructor (Util/RayTraceUtility.cs:478-528) and the
+ * per-hit collider/material lookups (Tracer/WhittedTracer.cs:43-88). */
+int vrt_set_scene(vrt_ctx* ctx, const vrt_scene_desc* scene);
+
+/* Replaces InitPlane/InitTexture + rayOrigin (RayTracerUnity.cs:273-285,358-394). */
+int vrt_set_camera(vrt_ctx* ctx, const vrt_camera* cam);
+
+/* Whole frame: the loop Update → DoRayTraceArchitecture → UpdateScene over every pixel
+ * (RayTracerUnity.cs:312-352,565-597,607-617).  rgba_out = width*height*4 floats
+ * (PixelColorData layout, index h*width+v), hit_id_out = width*height int32 primary
+ * primitive ids of sample 0 (may be NULL). */
+int vrt_render(vrt_ctx* ctx, const vrt_params* params, float* rgba_out,
+               int32_t* hit_id_out, vrt_stats* stats_out);
+
+/* Same, with the outputs left in device memory (rgba_dev, hit_id_dev are device pointers
+ * on the context's GPU; hit_id_dev may be NULL).  stream = a hipStream_t or NULL.  The call
+ * enqueues and returns; stats_out (may be NULL) is then complete only for gpu_ms = 0 and
+ * ray counts are fetched by vrt_fetch_stats after the caller has synchronised. */
+int vrt_render_device(vrt_ctx* ctx, const vrt_params* params, void* rgba_dev,
+                      void* hit_id_dev, void* stream);
+int vrt_fetch_stats(vrt_ctx* ctx, vrt_stats* stats_out);
+
+/* Single-step VR mode: one pixel, optionally one sample (sample < 0 = all samples,
+ * averaged and tone-mapped like a frame pixel).  Replaces one DoRayTraceArchitecture
+ * coroutine and fills the polyline UpdateScene draws (RayTracerUnity.cs:565-597,620-654).
+ * Also serves legacy AbstractTracer.TraceRay callers (Tracer/AbstractTracer.cs:7-11). */
+int vrt_trace_pixel(vrt_ctx* ctx, const vrt_params* params, int h, int v, int sample,
+                    vrt_path_seg* segs, int cap, int* n_out, float rgba[4],
+                    int32_t* hit_id_out);
+
+/* Host-side sampler tables (Sampler/{Regular,Random,Jittered,NRooks,MultiJittered,Hammersley}Sampler.cs, Sampler/AbstractSampler.cs:37-52,143-182):
+ * writes n_sets * n_samples (x,y) pairs in access order.  UnityEngine.Random is replaced
+ * by PCG32 seeded with `seed`.  Needs no GPU. */
+int vrt_sampler_table(int sampler, int n_samples, int n_sets, float h_step, float v_step,
+                      uint64_t seed, float* offsets_out);
+
+/* Sample-set choice per pixel (stands in for the shared `_count`/`_jump` state of
+ * Sampler/AbstractSampler.cs:149-153, which is not reproducible). */
+uint32_t vrt_pixel_set(uint32_t seed, uint32_t pixel, uint32_t n_sets);
+
+int vrt_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VRT_H */

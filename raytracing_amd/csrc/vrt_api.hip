@@ -1,0 +1,485 @@
+// C ABI of libvrt.so (include/vrt.h): context, scene/camera upload, render calls.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "vrt_launch.h"
+
+// Scenes with at most this many primitives are traced by the brute-force loop whose
+// primitive data stays in scalar registers; larger ones get the LBVH.
+static const uint32_t kBruteMaxPrims = 48;
+
+struct vrt_ctx {
+    int device = 0;
+    std::string err;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // scene
+    float4 *d_sph = nullptr, *d_box = nullptr, *d_tri = nullptr, *d_mat = nullptr, *d_bvh = nullptr;
+    int* d_prim_mat = nullptr;
+    DevScene scene;
+    bool have_scene = false, use_bvh = false;
+    float bvh_ms = 0.f;
+    int bvh_depth = 0;
+    // camera
+    DevCam cam;
+    bool have_cam = false;
+    // per-call buffers
+    float2* d_offsets = nullptr; size_t offsets_cap = 0;
+    unsigned long long* d_ctr = nullptr;
+    float4* d_rgba = nullptr; int* d_hit = nullptr; size_t fb_cap = 0;
+    int* d_rec_pixels = nullptr; vrt_path_seg* d_segs = nullptr; int* d_seg_counts = nullptr;
+    size_t rec_px_cap = 0, rec_seg_cap = 0;
+    float4* d_px_rgba = nullptr; int* d_px_hit = nullptr;
+    // wavefront workspace
+    WfWorkspace wf; size_t wf_pixels = 0; bool wf_two = false;
+    // last call
+    uint64_t last_pixels = 0; int last_mode = 0;
+    bool timed = false;
+};
+
+static int fail(vrt_ctx* c, int code, const std::string& msg)
+{
+    if (c) c->err = msg;
+    return code;
+}
+
+#define HIPCHK(c, expr)                                                                     \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return fail(c, VRT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+extern "C" int vrt_abi_version(void) { return VRT_ABI_VERSION; }
+
+extern "C" const char* vrt_last_error(vrt_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+extern "C" void vrt_shading_defaults(vrt_shading* s)
+{
+    if (!s) return;
+    s->solid_ka = 0.5f; s->solid_kd = 0.5f; s->solid_ks = 0.f; s->solid_exp = 1.f;
+    s->metal_ka = 0.25f; s->metal_kd = 0.5f; s->metal_ks = 0.15f; s->metal_exp = 100.f; s->metal_kr = 0.75f;
+    s->metal_cr[0] = s->metal_cr[1] = s->metal_cr[2] = s->metal_cr[3] = 1.f;
+    s->glass_ka = 0.5f; s->glass_kd = 0.5f; s->glass_ks = 0.2f; s->glass_exp = 1.f;
+    s->glass_eta_in = 1.5f; s->glass_eta_out = 1.f;
+    s->ao_min_amount[0] = s->ao_min_amount[1] = s->ao_min_amount[2] = 0.05f; s->ao_min_amount[3] = 1.f;
+    s->ao_ls = 1.f;
+    s->ao_color[0] = s->ao_color[1] = s->ao_color[2] = s->ao_color[3] = 1.f;
+}
+
+extern "C" void vrt_params_defaults(vrt_params* p)
+{
+    if (!p) return;
+    memset(p, 0, sizeof *p);
+    p->spp = 1; p->n_sets = 1; p->max_depth = 10; p->range = 30.f;
+    p->mode = VRT_MODE_AUTO; p->tile_count = 1; p->tile_rows = 8;
+}
+
+extern "C" int vrt_create(int device, vrt_ctx** out)
+{
+    if (!out) return VRT_ERR_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return VRT_ERR_NO_DEVICE;
+    if (device < 0 || device >= n) return VRT_ERR_INVALID;
+    vrt_ctx* c = new vrt_ctx();
+    c->device = device;
+    memset(&c->scene, 0, sizeof c->scene);
+    memset(&c->cam, 0, sizeof c->cam);
+    memset(&c->wf, 0, sizeof c->wf);
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess ||
+        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
+        hipMalloc(&c->d_ctr, VRT_CTR_SLOTS * VRT_CTR_STRIDE * sizeof(unsigned long long)) != hipSuccess ||
+        hipMalloc(&c->d_px_rgba, sizeof(float4)) != hipSuccess ||
+        hipMalloc(&c->d_px_hit, sizeof(int)) != hipSuccess) {
+        delete c;
+        return VRT_ERR_HIP;
+    }
+    *out = c;
+    return VRT_OK;
+}
+
+static void free_scene(vrt_ctx* c)
+{
+    hipFree(c->d_sph); hipFree(c->d_box); hipFree(c->d_tri); hipFree(c->d_mat); hipFree(c->d_bvh);
+    hipFree(c->d_prim_mat);
+    c->d_sph = c->d_box = c->d_tri = c->d_mat = c->d_bvh = nullptr;
+    c->d_prim_mat = nullptr;
+    c->have_scene = false;
+}
+
+static void free_wf(vrt_ctx* c)
+{
+    hipFree(c->wf.arena); hipFree(c->wf.sum); hipFree(c->wf.lacc); hipFree(c->wf.counts);
+    memset(&c->wf, 0, sizeof c->wf);
+    c->wf_pixels = 0;
+}
+
+extern "C" int vrt_destroy(vrt_ctx* c)
+{
+    if (!c) return VRT_ERR_INVALID;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    free_scene(c);
+    free_wf(c);
+    hipFree(c->d_offsets); hipFree(c->d_ctr); hipFree(c->d_rgba); hipFree(c->d_hit);
+    hipFree(c->d_rec_pixels); hipFree(c->d_segs); hipFree(c->d_seg_counts);
+    hipFree(c->d_px_rgba); hipFree(c->d_px_hit);
+    hipEventDestroy(c->ev0); hipEventDestroy(c->ev1);
+    hipStreamDestroy(c->stream);
+    delete c;
+    return VRT_OK;
+}
+
+template <typename T>
+static hipError_t upload(T** dst, const std::vector<T>& src)
+{
+    *dst = nullptr;
+    if (src.empty()) return hipSuccess;
+    hipError_t e = hipMalloc(dst, src.size() * sizeof(T));
+    if (e != hipSuccess) return e;
+    return hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice);
+}
+
+extern "C" int vrt_set_scene(vrt_ctx* c, const vrt_scene_desc* d)
+{
+    if (!c || !d) return fail(c, VRT_ERR_INVALID, "null argument");
+    if ((d->n_spheres && !d->spheres) || (d->n_boxes && !d->boxes) ||
+        (d->n_triangles && (!d->indices || !d->vertices)) || !d->n_materials || !d->materials ||
+        (d->n_lights && !d->lights))
+        return fail(c, VRT_ERR_INVALID, "scene arrays missing");
+    if (d->n_lights > VRT_MAX_LIGHTS) return fail(c, VRT_ERR_CAPACITY, "more than VRT_MAX_LIGHTS lights");
+    uint64_t n_prims64 = (uint64_t)d->n_spheres + d->n_boxes + d->n_triangles;
+    if (n_prims64 == 0 || n_prims64 > 0x3fffffffu) return fail(c, VRT_ERR_INVALID, "primitive count out of range");
+    uint32_t n_prims = (uint32_t)n_prims64;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+
+    std::vector<float4> sph(d->n_spheres), box(4 * (size_t)d->n_boxes), tri(3 * (size_t)d->n_triangles),
+        mat(d->n_materials);
+    std::vector<int> pm(n_prims);
+    for (uint32_t i = 0; i < d->n_materials; ++i) {
+        const vrt_material& m = d->materials[i];
+        if (m.type < VRT_MAT_SOLID || m.type > VRT_MAT_DIELECTRIC) return fail(c, VRT_ERR_INVALID, "bad material type");
+        float4 v; v.x = m.color[0]; v.y = m.color[1]; v.z = m.color[2];
+        int t = m.type; memcpy(&v.w, &t, 4);
+        mat[i] = v;
+    }
+    auto mat_ok = [&](int32_t m) { return m >= 0 && (uint32_t)m < d->n_materials; };
+    for (uint32_t i = 0; i < d->n_spheres; ++i) {
+        const vrt_sphere& s = d->spheres[i];
+        if (!mat_ok(s.material)) return fail(c, VRT_ERR_INVALID, "sphere material out of range");
+        sph[i] = make_float4(s.center[0], s.center[1], s.center[2], s.radius);
+        pm[i] = s.material;
+    }
+    for (uint32_t i = 0; i < d->n_boxes; ++i) {
+        const vrt_box& b = d->boxes[i];
+        if (!mat_ok(b.material)) return fail(c, VRT_ERR_INVALID, "box material out of range");
+        box[4 * i + 0] = make_float4(b.center[0], b.center[1], b.center[2], b.half[0]);
+        box[4 * i + 1] = make_float4(b.axis[0], b.axis[1], b.axis[2], b.half[1]);
+        box[4 * i + 2] = make_float4(b.axis[3], b.axis[4], b.axis[5], b.half[2]);
+        box[4 * i + 3] = make_float4(b.axis[6], b.axis[7], b.axis[8], 0.f);
+        pm[d->n_spheres + i] = b.material;
+    }
+    for (uint32_t i = 0; i < d->n_triangles; ++i) {
+        const uint32_t* ix = d->indices + 3 * (size_t)i;
+        if (ix[0] >= d->n_vertices || ix[1] >= d->n_vertices || ix[2] >= d->n_vertices)
+            return fail(c, VRT_ERR_INVALID, "triangle index out of range");
+        const float* a = d->vertices + 3 * (size_t)ix[0];
+        const float* b = d->vertices + 3 * (size_t)ix[1];
+        const float* cc = d->vertices + 3 * (size_t)ix[2];
+        int32_t m = d->tri_material ? d->tri_material[i] : 0;
+        if (!mat_ok(m)) return fail(c, VRT_ERR_INVALID, "triangle material out of range");
+        // edges in float32, one rounding each, exactly as a per-ray v1 - v0 would give
+        tri[3 * (size_t)i + 0] = make_float4(a[0], a[1], a[2], 0.f);
+        tri[3 * (size_t)i + 1] = make_float4(b[0] - a[0], b[1] - a[1], b[2] - a[2], 0.f);
+        tri[3 * (size_t)i + 2] = make_float4(cc[0] - a[0], cc[1] - a[1], cc[2] - a[2], 0.f);
+        pm[d->n_spheres + d->n_boxes + i] = m;
+    }
+
+    free_scene(c);
+    HIPCHK(c, upload(&c->d_sph, sph));
+    HIPCHK(c, upload(&c->d_box, box));
+    HIPCHK(c, upload(&c->d_tri, tri));
+    HIPCHK(c, upload(&c->d_mat, mat));
+    HIPCHK(c, upload(&c->d_prim_mat, pm));
+
+    DevScene& S = c->scene;
+    memset(&S, 0, sizeof S);
+    S.n_sph = (int)d->n_spheres; S.n_box = (int)d->n_boxes; S.n_tri = (int)d->n_triangles;
+    S.n_prims = (int)n_prims;
+    S.sph = c->d_sph; S.box = c->d_box; S.tri = c->d_tri; S.prim_mat = c->d_prim_mat; S.mat = c->d_mat;
+    S.n_lights = (int)d->n_lights;
+    for (uint32_t i = 0; i < d->n_lights; ++i) {
+        const vrt_light& l = d->lights[i];
+        if (l.type != VRT_LIGHT_DIRECTIONAL && l.type != VRT_LIGHT_POINT) return fail(c, VRT_ERR_INVALID, "bad light type");
+        DevLight& o = S.lights[i];
+        o.type = l.type; o.vx = l.vec[0]; o.vy = l.vec[1]; o.vz = l.vec[2]; o.ls = l.ls;
+        o.cr = l.color[0]; o.cg = l.color[1]; o.cb = l.color[2]; o.cast = l.cast_shadows;
+        o.lx = l.location[0]; o.ly = l.location[1]; o.lz = l.location[2];
+    }
+    S.sh = d->shading;
+
+    c->use_bvh = n_prims > kBruteMaxPrims;
+    c->bvh_ms = 0.f; c->bvh_depth = 0;
+    if (c->use_bvh) {
+        HIPCHK(c, hipMalloc(&c->d_bvh, 4 * (size_t)(n_prims - 1) * sizeof(float4)));
+        S.bvh = c->d_bvh;
+        hipError_t e = vrt_build_lbvh(S, c->d_bvh, &c->bvh_depth, &c->bvh_ms, c->stream);
+        if (e != hipSuccess) return fail(c, VRT_ERR_HIP, std::string("LBVH build: ") + hipGetErrorString(e));
+        if (c->bvh_depth > VRT_BVH_STACK - 2)
+            return fail(c, VRT_ERR_CAPACITY, "LBVH deeper than the traversal stack");
+    }
+    c->have_scene = true;
+    return VRT_OK;
+}
+
+extern "C" int vrt_set_camera(vrt_ctx* c, const vrt_camera* cam)
+{
+    if (!c || !cam) return fail(c, VRT_ERR_INVALID, "null argument");
+    if (cam->width <= 0 || cam->height <= 0 || (int64_t)cam->width * cam->height > (1ll << 30))
+        return fail(c, VRT_ERR_INVALID, "frame size out of range");
+    DevCam& d = c->cam;
+    d.ox = cam->origin[0]; d.oy = cam->origin[1]; d.oz = cam->origin[2];
+    // PlaneBorderPoints[0] - rayOrigin, rounded once like the C# Vector3 subtraction
+    d.bx = cam->p0[0] - cam->origin[0]; d.by = cam->p0[1] - cam->origin[1]; d.bz = cam->p0[2] - cam->origin[2];
+    d.xx = cam->x_axis[0]; d.xy = cam->x_axis[1]; d.xz = cam->x_axis[2];
+    d.yx = cam->y_axis[0]; d.yy = cam->y_axis[1]; d.yz = cam->y_axis[2];
+    d.width = cam->width; d.height = cam->height;
+    c->have_cam = true;
+    return VRT_OK;
+}
+
+static int owned_rows(int H, int index, int count, int rows)
+{
+    if (count <= 1) return H;
+    int n = 0;
+    for (int s = index; s * rows < H; s += count) {
+        int a = s * rows, b = a + rows < H ? a + rows : H;
+        n += b - a;
+    }
+    return n;
+}
+
+// Validates params, uploads the offset table and fills DevParams.
+static int prepare(vrt_ctx* c, const vrt_params* p, DevParams* out)
+{
+    if (!c->have_scene || !c->have_cam) return fail(c, VRT_ERR_STATE, "scene or camera not set");
+    if (p->spp < 1 || p->spp > 65536) return fail(c, VRT_ERR_INVALID, "spp out of range");
+    if (p->max_depth < 0 || p->max_depth > VRT_MAX_DEPTH) return fail(c, VRT_ERR_CAPACITY, "max_depth out of range");
+    if (!(p->range > 0.f)) return fail(c, VRT_ERR_INVALID, "range must be positive");
+    if (p->offsets && p->n_sets < 1) return fail(c, VRT_ERR_INVALID, "n_sets must be >= 1");
+    int tcount = p->tile_count > 1 ? p->tile_count : 1;
+    if (tcount > 1 && (p->tile_index < 0 || p->tile_index >= tcount || p->tile_rows < 1))
+        return fail(c, VRT_ERR_INVALID, "bad tile parameters");
+    DevParams& P = *out;
+    memset(&P, 0, sizeof P);
+    P.spp = p->spp; P.n_sets = p->offsets ? p->n_sets : 1; P.seed = p->seed;
+    P.max_depth = p->max_depth; P.range = p->range; P.flags = p->flags;
+    P.tile_index = tcount > 1 ? p->tile_index : 0; P.tile_count = tcount;
+    P.tile_rows = p->tile_rows > 0 ? p->tile_rows : 8;
+    P.local_rows = owned_rows(c->cam.height, P.tile_index, tcount, P.tile_rows);
+    P.offsets = nullptr;
+    if (p->offsets) {
+        size_t n = (size_t)p->n_sets * p->spp;
+        if (n > c->offsets_cap) {
+            HIPCHK(c, hipFree(c->d_offsets));
+            c->d_offsets = nullptr; c->offsets_cap = 0;
+            HIPCHK(c, hipMalloc(&c->d_offsets, n * sizeof(float2)));
+            c->offsets_cap = n;
+        }
+        HIPCHK(c, hipMemcpyAsync(c->d_offsets, p->offsets, n * sizeof(float2), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream)); // the caller's table may be reused right away
+        P.offsets = c->d_offsets;
+    }
+    return VRT_OK;
+}
+
+static int ensure_wf(vrt_ctx* c, size_t pixels, bool two)
+{
+    if (c->wf_pixels >= pixels && (c->wf_two || !two)) return VRT_OK;
+    free_wf(c);
+    size_t cap = pixels * (two ? 2 : 1);
+    HIPCHK(c, hipMalloc(&c->wf.arena, cap * 2 * VRT_QUEUE_ARRAYS * sizeof(float)));
+    for (int k = 0; k < 2; ++k) {
+        float* b = c->wf.arena + (size_t)k * cap * VRT_QUEUE_ARRAYS;
+        RayQueue& q = c->wf.q[k];
+        q.ox = b; q.oy = b + cap; q.oz = b + 2 * cap; q.dx = b + 3 * cap; q.dy = b + 4 * cap; q.dz = b + 5 * cap;
+        q.tr = b + 6 * cap; q.tg = b + 7 * cap; q.tb = b + 8 * cap;
+        q.pix = (int*)(b + 9 * cap); q.skip = (int*)(b + 10 * cap); q.meta = (int*)(b + 11 * cap);
+    }
+    c->wf.cap = cap;
+    HIPCHK(c, hipMalloc(&c->wf.sum, pixels * sizeof(float4)));
+    HIPCHK(c, hipMalloc(&c->wf.lacc, pixels * sizeof(float4)));
+    HIPCHK(c, hipMalloc(&c->wf.counts, (VRT_MAX_DEPTH + 3) * sizeof(int)));
+    c->wf_pixels = pixels; c->wf_two = two;
+    return VRT_OK;
+}
+
+// Enqueues one frame on `stream`.
+static int enqueue_frame(vrt_ctx* c, const vrt_params* p, const DevParams& P, float4* rgba, int* hit,
+                         hipStream_t stream)
+{
+    HIPCHK(c, hipMemsetAsync(c->d_ctr, 0, VRT_CTR_SLOTS * VRT_CTR_STRIDE * sizeof(unsigned long long), stream));
+    bool two = (p->flags & VRT_FIX_DIELECTRIC) != 0;
+    int mode = p->mode == VRT_MODE_WAVEFRONT ? VRT_MODE_WAVEFRONT : VRT_MODE_MEGAKERNEL;
+    if (mode == VRT_MODE_WAVEFRONT) {
+        size_t pixels = (size_t)P.local_rows * c->cam.width;
+        int rc = ensure_wf(c, pixels ? pixels : 1, two);
+        if (rc) return rc;
+        HIPCHK(c, vrt_launch_wavefront(c->scene, c->cam, P, c->use_bvh, two, c->wf, rgba, hit, c->d_ctr, stream));
+    } else {
+        HIPCHK(c, vrt_launch_mega(c->scene, c->cam, P, c->use_bvh, two, rgba, hit, c->d_ctr, stream));
+    }
+    c->last_pixels = (uint64_t)P.local_rows * c->cam.width;
+    c->last_mode = mode;
+    return VRT_OK;
+}
+
+static int read_stats(vrt_ctx* c, vrt_stats* s)
+{
+    std::vector<unsigned long long> h(VRT_CTR_SLOTS * VRT_CTR_STRIDE);
+    HIPCHK(c, hipMemcpy(h.data(), c->d_ctr, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    memset(s, 0, sizeof *s);
+    for (int i = 0; i < VRT_CTR_SLOTS; ++i)
+        for (int k = 0; k < VRT_RAY_CLASSES; ++k) s->rays[k] += h[i * VRT_CTR_STRIDE + k];
+    s->pixels = c->last_pixels;
+    s->bvh_build_ms = c->bvh_ms;
+    s->bvh_nodes = c->use_bvh ? (uint32_t)(c->scene.n_prims - 1) : 0;
+    s->mode_used = c->last_mode;
+    s->gpu_ms = 0.f;
+    if (c->timed) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) s->gpu_ms = ms;
+    }
+    return VRT_OK;
+}
+
+static int run_records(vrt_ctx* c, const vrt_params* p, const DevParams& P, const int* pixels, int n, int cap,
+                       int sample_sel, vrt_path_seg* out, int* counts_out, float4* rgba_dev, int* hit_dev,
+                       unsigned long long* ctr)
+{
+    if (n <= 0) return VRT_OK;
+    if (cap < 0) return fail(c, VRT_ERR_INVALID, "negative record capacity");
+    size_t total = c->cam.width * (size_t)c->cam.height;
+    for (int i = 0; i < n; ++i)
+        if (pixels[i] < 0 || (size_t)pixels[i] >= total) return fail(c, VRT_ERR_INVALID, "record pixel out of range");
+    if ((size_t)n > c->rec_px_cap) {
+        hipFree(c->d_rec_pixels); hipFree(c->d_seg_counts);
+        c->d_rec_pixels = nullptr; c->d_seg_counts = nullptr; c->rec_px_cap = 0;
+        HIPCHK(c, hipMalloc(&c->d_rec_pixels, n * sizeof(int)));
+        HIPCHK(c, hipMalloc(&c->d_seg_counts, n * sizeof(int)));
+        c->rec_px_cap = n;
+    }
+    size_t nseg = (size_t)n * (cap > 0 ? cap : 1);
+    if (nseg > c->rec_seg_cap) {
+        hipFree(c->d_segs); c->d_segs = nullptr; c->rec_seg_cap = 0;
+        HIPCHK(c, hipMalloc(&c->d_segs, nseg * sizeof(vrt_path_seg)));
+        c->rec_seg_cap = nseg;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_rec_pixels, pixels, n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    bool two = (p->flags & VRT_FIX_DIELECTRIC) != 0;
+    HIPCHK(c, vrt_launch_pixels(c->scene, c->cam, P, c->use_bvh, two, c->d_rec_pixels, n, sample_sel, c->d_segs,
+                                cap, c->d_seg_counts, rgba_dev, hit_dev, ctr, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (counts_out) HIPCHK(c, hipMemcpy(counts_out, c->d_seg_counts, n * sizeof(int), hipMemcpyDeviceToHost));
+    if (out && cap > 0)
+        HIPCHK(c, hipMemcpy(out, c->d_segs, (size_t)n * cap * sizeof(vrt_path_seg), hipMemcpyDeviceToHost));
+    return VRT_OK;
+}
+
+extern "C" int vrt_render(vrt_ctx* c, const vrt_params* p, float* rgba_out, int32_t* hit_id_out, vrt_stats* stats_out)
+{
+    if (!c || !p || !rgba_out) return fail(c, VRT_ERR_INVALID, "null argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    DevParams P;
+    int rc = prepare(c, p, &P);
+    if (rc) return rc;
+    if (p->n_record_pixels < 0 || (p->n_record_pixels > 0 && (!p->record_pixels || !p->record_count_out)))
+        return fail(c, VRT_ERR_INVALID, "record arguments missing");
+    size_t npix = (size_t)c->cam.width * c->cam.height;
+    if (npix > c->fb_cap) {
+        hipFree(c->d_rgba); hipFree(c->d_hit);
+        c->d_rgba = nullptr; c->d_hit = nullptr; c->fb_cap = 0;
+        HIPCHK(c, hipMalloc(&c->d_rgba, npix * sizeof(float4)));
+        HIPCHK(c, hipMalloc(&c->d_hit, npix * sizeof(int)));
+        c->fb_cap = npix;
+    }
+    if (P.tile_count > 1) { // rows of other ranks stay as the caller left them
+        HIPCHK(c, hipMemcpyAsync(c->d_rgba, rgba_out, npix * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+        if (hit_id_out)
+            HIPCHK(c, hipMemcpyAsync(c->d_hit, hit_id_out, npix * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    }
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    rc = enqueue_frame(c, p, P, c->d_rgba, c->d_hit, c->stream);
+    if (rc) return rc;
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    c->timed = true;
+    HIPCHK(c, hipMemcpyAsync(rgba_out, c->d_rgba, npix * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    if (hit_id_out)
+        HIPCHK(c, hipMemcpyAsync(hit_id_out, c->d_hit, npix * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (stats_out) { rc = read_stats(c, stats_out); if (rc) return rc; }
+    if (p->n_record_pixels > 0) {
+        rc = run_records(c, p, P, p->record_pixels, p->n_record_pixels, p->record_cap, -1, p->record_out,
+                         p->record_count_out, nullptr, nullptr, nullptr);
+        if (rc) return rc;
+    }
+    return VRT_OK;
+}
+
+extern "C" int vrt_render_device(vrt_ctx* c, const vrt_params* p, void* rgba_dev, void* hit_id_dev, void* stream)
+{
+    if (!c || !p || !rgba_dev) return fail(c, VRT_ERR_INVALID, "null argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    DevParams P;
+    int rc = prepare(c, p, &P);
+    if (rc) return rc;
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    c->timed = false;
+    return enqueue_frame(c, p, P, (float4*)rgba_dev, (int*)hit_id_dev, s);
+}
+
+extern "C" int vrt_fetch_stats(vrt_ctx* c, vrt_stats* stats_out)
+{
+    if (!c || !stats_out) return fail(c, VRT_ERR_INVALID, "null argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    return read_stats(c, stats_out);
+}
+
+extern "C" int vrt_trace_pixel(vrt_ctx* c, const vrt_params* p, int h, int v, int sample, vrt_path_seg* segs,
+                               int cap, int* n_out, float rgba[4], int32_t* hit_id_out)
+{
+    if (!c || !p || !rgba) return fail(c, VRT_ERR_INVALID, "null argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    DevParams P;
+    int rc = prepare(c, p, &P);
+    if (rc) return rc;
+    if (h < 0 || h >= c->cam.height || v < 0 || v >= c->cam.width) return fail(c, VRT_ERR_INVALID, "pixel out of range");
+    if (sample >= p->spp) return fail(c, VRT_ERR_INVALID, "sample out of range");
+    if (cap < 0 || (cap > 0 && !segs)) return fail(c, VRT_ERR_INVALID, "bad record buffer");
+    int pix = h * c->cam.width + v, n = 0;
+    HIPCHK(c, hipMemsetAsync(c->d_ctr, 0, VRT_CTR_SLOTS * VRT_CTR_STRIDE * sizeof(unsigned long long), c->stream));
+    rc = run_records(c, p, P, &pix, 1, cap, sample < 0 ? -1 : sample, segs, &n, c->d_px_rgba, c->d_px_hit, c->d_ctr);
+    if (rc) return rc;
+    float4 col; int id;
+    HIPCHK(c, hipMemcpy(&col, c->d_px_rgba, sizeof col, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(&id, c->d_px_hit, sizeof id, hipMemcpyDeviceToHost));
+    rgba[0] = col.x; rgba[1] = col.y; rgba[2] = col.z; rgba[3] = col.w;
+    if (hit_id_out) *hit_id_out = id;
+    if (n_out) *n_out = n;
+    c->last_pixels = 1; c->last_mode = VRT_MODE_MEGAKERNEL; c->timed = false;
+    return VRT_OK;
+}
+
+extern "C" uint32_t vrt_pixel_set(uint32_t seed, uint32_t pixel, uint32_t n_sets)
+{
+    if (n_sets <= 1u) return 0u;
+    uint32_t x = pixel ^ seed;
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x % n_sets;
+}

@@ -1,0 +1,74 @@
+// Device-side data layout of libvrt (gfx950).  Shared by the kernels and the C-ABI host code.
+//
+// Layout in HBM:
+//   sph   float4[n_sph]        (cx, cy, cz, r)
+//   box   float4[4*n_box]      (c.xyz, h0) (A0.xyz, h1) (A1.xyz, h2) (A2.xyz, 0)
+//   tri   float4[3*n_tri]      (v0.xyz, 0) (e1.xyz, 0) (e2.xyz, 0), e1 = v1-v0, e2 = v2-v0
+//   prim_mat int[n_prims]      material index per primitive id (spheres, boxes, triangles)
+//   mat   float4[n_mat]        (r, g, b, type-as-int-bits)
+//   bvh   float4[4*(n_prims-1)] binary LBVH, one 64-byte node per internal node holding the
+//                              boxes of both children:
+//                              (lo0.xyz, hi0.x) (hi0.yz, lo1.xy) (lo1.z, hi1.xyz) (c0, c1, -, -)
+//                              child >= 0: internal node index, child < 0: leaf, primitive = ~child
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/vrt.h"
+
+struct DevLight {
+    int type;
+    float vx, vy, vz;
+    float ls;
+    float cr, cg, cb;
+    int cast;
+    float lx, ly, lz;
+};
+
+struct DevScene {
+    int n_sph, n_box, n_tri, n_prims;
+    const float4* sph;
+    const float4* box;
+    const float4* tri;
+    const int* prim_mat;
+    const float4* mat;
+    const float4* bvh;
+    int n_lights;
+    DevLight lights[VRT_MAX_LIGHTS];
+    vrt_shading sh;
+};
+
+struct DevCam {
+    float ox, oy, oz;
+    float bx, by, bz; // P0 - O
+    float xx, xy, xz;
+    float yx, yy, yz;
+    int width, height;
+};
+
+struct DevParams {
+    int spp, n_sets;
+    const float2* offsets; // n_sets*spp or null
+    unsigned seed;
+    int max_depth;
+    float range;
+    unsigned flags;
+    // strip sharding: local row r -> global row
+    int tile_index, tile_count, tile_rows;
+    int local_rows; // rows this call renders
+};
+
+// Per-call ray counters: 256 slots x 8 words to spread atomic traffic, summed by the host.
+#define VRT_CTR_SLOTS 256
+#define VRT_CTR_STRIDE 8
+
+// Ray queue for the wavefront pipeline, struct of arrays, one entry per live ray.
+struct RayQueue {
+    float *ox, *oy, *oz, *dx, *dy, *dz; // origin, unit direction
+    float *tr, *tg, *tb;                // path throughput
+    int *pix;                           // local pixel index
+    int *skip;                          // primitive the ray was spawned on
+    int *meta;                          // depth | kind << 8
+};
+#define VRT_QUEUE_ARRAYS 12
+
+#define VRT_BVH_STACK 64

@@ -1,0 +1,128 @@
+// Render kernels of libvrt (gfx950) and their launchers.
+//
+// k_mega      one lane = one pixel through all samples and bounces (single launch).
+// k_pixels    the same per-pixel routine with path recording, for a short list of pixels.
+// k_wf_*      wavefront pipeline: per-bounce kernels over compacted SoA ray queues.
+#include "vrt_trace.h"
+#include "vrt_launch.h"
+
+// ------------------------------------------------------------------ helpers
+
+__device__ __forceinline__ int local_to_global_row(const DevParams& P, int r)
+{
+    if (P.tile_count <= 1) return r;
+    return ((r / P.tile_rows) * P.tile_count + P.tile_index) * P.tile_rows + (r % P.tile_rows);
+}
+
+__device__ __forceinline__ unsigned wave_sum(unsigned v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Adds this block's counters into one of VRT_CTR_SLOTS slots (one atomic per class per block).
+__device__ __forceinline__ void flush_counters(const Counters& C, unsigned long long* ctr, unsigned block_linear)
+{
+    __shared__ unsigned s_ctr[VRT_RAY_CLASSES];
+    if (threadIdx.x < VRT_RAY_CLASSES) s_ctr[threadIdx.x] = 0;
+    __syncthreads();
+    unsigned v[VRT_RAY_CLASSES] = {C.precheck, C.primary, C.reflect, C.transmit, C.shadow, C.ao};
+#pragma unroll
+    for (int k = 0; k < VRT_RAY_CLASSES; ++k) {
+        unsigned s = wave_sum(v[k]);
+        if ((threadIdx.x & 63) == 0 && s) atomicAdd(&s_ctr[k], s);
+    }
+    __syncthreads();
+    if (threadIdx.x < VRT_RAY_CLASSES && s_ctr[threadIdx.x])
+        atomicAdd(&ctr[(block_linear % VRT_CTR_SLOTS) * VRT_CTR_STRIDE + threadIdx.x],
+                  (unsigned long long)s_ctr[threadIdx.x]);
+}
+
+// ------------------------------------------------------------------ megakernel
+
+// Block = 256 lanes = 4 waves; each wave owns an 8x8 pixel tile (coherent rays, and eight
+// full 128-byte framebuffer lines per wave store); a block covers 32x8 pixels.
+// Blocks are renumbered so that the 8 blocks dealt round-robin to the 8 XCDs come from 8
+// separate bands of the image and each XCD's L2 keeps seeing neighbouring tiles.
+template <bool BVH, bool TWOCHILD>
+__global__ __launch_bounds__(256) void k_mega(DevScene S, DevCam cam, DevParams P, float4* __restrict__ rgba,
+                                              int* __restrict__ hit_id, unsigned long long* ctr,
+                                              int blocks_x, int n_blocks)
+{
+    unsigned bid = blockIdx.x;
+    {   // bijective XCD remap: label = bid % 8 selects a contiguous band of block ids
+        unsigned q = n_blocks / 8, r = n_blocks % 8, xcd = bid % 8, k = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    int bx = bid % blocks_x, by = bid / blocks_x;
+    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int v = bx * 32 + wave * 8 + (lane & 7);
+    int r = by * 8 + (lane >> 3);
+    int h = local_to_global_row(P, r);
+    Counters C = {0, 0, 0, 0, 0, 0};
+    Recorder R; R.segs = nullptr; R.cap = 0; R.n = 0; R.sample = 0;
+    if (v < cam.width && r < P.local_rows && h < cam.height) {
+        int id;
+        float4 c = trace_pixel_dev<BVH, false, TWOCHILD>(S, cam, P, h, v, -1, id, C, R);
+        size_t idx = (size_t)h * cam.width + v; // RayTracerUnity.cs:442
+        rgba[idx] = c;
+        if (hit_id) hit_id[idx] = id;
+    }
+    flush_counters(C, ctr, blockIdx.x);
+}
+
+// ------------------------------------------------------------------ recorded pixels
+
+template <bool BVH, bool TWOCHILD>
+__global__ __launch_bounds__(64) void k_pixels(DevScene S, DevCam cam, DevParams P, const int* __restrict__ pixels,
+                                               int n_pixels, int sample_sel, vrt_path_seg* __restrict__ segs,
+                                               int cap, int* __restrict__ seg_counts, float4* __restrict__ rgba_out,
+                                               int* __restrict__ hit_out, unsigned long long* ctr)
+{
+    int i = blockIdx.x * 64 + threadIdx.x;
+    Counters C = {0, 0, 0, 0, 0, 0};
+    if (i < n_pixels) {
+        int pix = pixels[i];
+        int h = pix / cam.width, v = pix % cam.width;
+        Recorder R; R.segs = segs + (size_t)i * cap; R.cap = cap; R.n = 0; R.sample = 0;
+        int id;
+        float4 c = trace_pixel_dev<BVH, true, TWOCHILD>(S, cam, P, h, v, sample_sel, id, C, R);
+        seg_counts[i] = R.n;
+        if (rgba_out) rgba_out[i] = c;
+        if (hit_out) hit_out[i] = id;
+    }
+    if (ctr) flush_counters(C, ctr, blockIdx.x);
+}
+
+// ------------------------------------------------------------------ launchers
+
+static inline int div_up(int a, int b) { return (a + b - 1) / b; }
+
+hipError_t vrt_launch_mega(const DevScene& S, const DevCam& cam, const DevParams& P, bool bvh, bool twochild,
+                           float4* rgba, int* hit_id, unsigned long long* ctr, hipStream_t stream)
+{
+    int blocks_x = div_up(cam.width, 32), blocks_y = div_up(P.local_rows, 8);
+    int n_blocks = blocks_x * blocks_y;
+    if (n_blocks <= 0) return hipSuccess;
+    dim3 grid(n_blocks), block(256);
+#define VRT_GO(B, T) hipLaunchKernelGGL((k_mega<B, T>), grid, block, 0, stream, S, cam, P, rgba, hit_id, ctr, blocks_x, n_blocks)
+    if (bvh) { if (twochild) VRT_GO(true, true); else VRT_GO(true, false); }
+    else     { if (twochild) VRT_GO(false, true); else VRT_GO(false, false); }
+#undef VRT_GO
+    return hipGetLastError();
+}
+
+hipError_t vrt_launch_pixels(const DevScene& S, const DevCam& cam, const DevParams& P, bool bvh, bool twochild,
+                             const int* pixels, int n_pixels, int sample_sel, vrt_path_seg* segs, int cap,
+                             int* seg_counts, float4* rgba_out, int* hit_out, unsigned long long* ctr,
+                             hipStream_t stream)
+{
+    if (n_pixels <= 0) return hipSuccess;
+    dim3 grid(div_up(n_pixels, 64)), block(64);
+#define VRT_GO(B, T) hipLaunchKernelGGL((k_pixels<B, T>), grid, block, 0, stream, S, cam, P, pixels, n_pixels, sample_sel, segs, cap, seg_counts, rgba_out, hit_out, ctr)
+    if (bvh) { if (twochild) VRT_GO(true, true); else VRT_GO(true, false); }
+    else     { if (twochild) VRT_GO(false, true); else VRT_GO(false, false); }
+#undef VRT_GO
+    return hipGetLastError();
+}

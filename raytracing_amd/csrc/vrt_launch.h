@@ -1,0 +1,29 @@
+// Host-callable launchers implemented in vrt_kernels.hip / vrt_bvh.hip / vrt_wavefront.hip.
+#pragma once
+#include "vrt_device.h"
+
+hipError_t vrt_launch_mega(const DevScene& S, const DevCam& cam, const DevParams& P, bool bvh, bool twochild,
+                           float4* rgba, int* hit_id, unsigned long long* ctr, hipStream_t stream);
+
+hipError_t vrt_launch_pixels(const DevScene& S, const DevCam& cam, const DevParams& P, bool bvh, bool twochild,
+                             const int* pixels, int n_pixels, int sample_sel, vrt_path_seg* segs, int cap,
+                             int* seg_counts, float4* rgba_out, int* hit_out, unsigned long long* ctr,
+                             hipStream_t stream);
+
+// Wavefront pipeline workspace: ray queues (two, ping-pong), per-pixel accumulators, counters.
+struct WfWorkspace {
+    RayQueue q[2];
+    float* arena;       // backing store of both queues
+    size_t cap;         // rays per queue
+    float4* sum;        // per local pixel: running sum over samples (xyz)
+    float4* lacc;       // per local pixel: radiance of the sample in flight (xyz), w = hit flag
+    int* counts;        // queue sizes per depth, VRT_MAX_DEPTH + 3 ints
+};
+
+hipError_t vrt_launch_wavefront(const DevScene& S, const DevCam& cam, const DevParams& P, bool bvh,
+                                bool twochild, const WfWorkspace& W, float4* rgba, int* hit_id,
+                                unsigned long long* ctr, hipStream_t stream);
+
+// LBVH build on the device.  prim arrays are those of DevScene; writes 4*(n_prims-1) float4
+// nodes to `nodes`.  Returns the tree depth in *depth_out.  Synchronises the stream.
+hipError_t vrt_build_lbvh(const DevScene& S, float4* nodes, int* depth_out, float* ms_out, hipStream_t stream);

@@ -1,0 +1,543 @@
+// Device functions of the tracing loop (gfx950, wave64).  Compiled with -ffp-contract=off:
+// every multiply and add rounds separately, in the order written, because hit decisions must
+// be bit-identical to the reference's float arithmetic.
+//
+// Citations: /root/reference/VisualRayTrace/Assets/Scripts/RayTracer/<file>:<lines>.
+#pragma once
+#include "vrt_device.h"
+
+struct f3 { float x, y, z; };
+__device__ __forceinline__ f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ f3 operator-(f3 a) { return mk3(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ f3 operator*(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ f3 operator/(f3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s); }
+// UnityEngine.Vector3.Dot / Cross / Magnitude / Normalize
+__device__ __forceinline__ float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ f3 cross3(f3 a, f3 b)
+{
+    return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ float mag3(f3 a) { return sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }
+__device__ __forceinline__ f3 normalize3(f3 a)
+{
+    float m = mag3(a);
+    if (m > 1e-5f) return a / m;
+    return mk3(0.f, 0.f, 0.f);
+}
+__device__ __forceinline__ bool is_zero3(f3 a) { return a.x == 0.f && a.y == 0.f && a.z == 0.f; }
+__device__ __forceinline__ f3 xyz(float4 v) { return mk3(v.x, v.y, v.z); }
+
+// Same mixing function as vrt_pixel_set on the host.
+__device__ __forceinline__ unsigned pixel_set_dev(unsigned seed, unsigned pixel, unsigned n_sets)
+{
+    if (n_sets <= 1u) return 0u;
+    unsigned x = pixel ^ seed;
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x % n_sets;
+}
+
+// ------------------------------------------------------------------ colliders
+// Semantics (Unity Physics.Raycast as documented): closest collider with 0 <= t <= maxd; a
+// collider containing the origin is not reported; triangles are single sided; equal t goes to
+// the lowest primitive id.
+
+__device__ __forceinline__ bool hit_sphere(float4 s, f3 o, f3 d, float maxd, float& t)
+{
+    f3 oc = o - xyz(s);
+    float b = dot3(oc, d);
+    float cc = dot3(oc, oc) - s.w * s.w;
+    float disc = b * b - cc;
+    if (!(cc > 0.f && b < 0.f && disc >= 0.f)) return false;
+    t = -b - sqrtf(disc);
+    return t >= 0.f && t <= maxd;
+}
+
+// aux = axis | (entered through the +axis face ? 4 : 0)
+__device__ __forceinline__ bool hit_box(float4 b0, float4 b1, float4 b2, float4 b3, f3 o, f3 d,
+                                        float maxd, float& t, int& aux)
+{
+    f3 p = o - xyz(b0);
+    float lo0 = dot3(p, xyz(b1)), lo1 = dot3(p, xyz(b2)), lo2 = dot3(p, xyz(b3));
+    float ld0 = dot3(d, xyz(b1)), ld1 = dot3(d, xyz(b2)), ld2 = dot3(d, xyz(b3));
+    float h0 = b0.w, h1 = b1.w, h2 = b2.w;
+    bool inside = (fabsf(lo0) <= h0) && (fabsf(lo1) <= h1) && (fabsf(lo2) <= h2);
+    if (inside) return false;
+    float tn = -INFINITY, tf = INFINITY;
+    int ax = -1;
+#define VRT_SLAB(K, LO, LD, H)                                              \
+    if (LD == 0.f) { if (fabsf(LO) > H) return false; }                     \
+    else {                                                                  \
+        float inv = 1.f / LD;                                               \
+        float t1 = (-H - LO) * inv, t2 = (H - LO) * inv;                    \
+        float nr = LD > 0.f ? t1 : t2, fr = LD > 0.f ? t2 : t1;             \
+        if (nr > tn) { tn = nr; ax = K | (LD > 0.f ? 0 : 4); }              \
+        if (fr < tf) tf = fr;                                               \
+    }
+    VRT_SLAB(0, lo0, ld0, h0)
+    VRT_SLAB(1, lo1, ld1, h1)
+    VRT_SLAB(2, lo2, ld2, h2)
+#undef VRT_SLAB
+    if (ax < 0) return false;
+    if (!(tn <= tf)) return false;
+    if (!(tn >= 0.f && tn <= maxd)) return false;
+    t = tn; aux = ax;
+    return true;
+}
+
+__device__ __forceinline__ bool hit_tri(f3 v0, f3 e1, f3 e2, f3 o, f3 d, float maxd, float& t)
+{
+    f3 pvec = cross3(d, e2);
+    float det = dot3(e1, pvec);
+    if (!(det > 0.f)) return false;
+    f3 tvec = o - v0;
+    float u = dot3(tvec, pvec);
+    if (u < 0.f || u > det) return false;
+    f3 qvec = cross3(tvec, e1);
+    float v = dot3(d, qvec);
+    if (v < 0.f || u + v > det) return false;
+    t = dot3(e2, qvec) / det;
+    return t >= 0.f && t <= maxd;
+}
+
+struct Hit {
+    float t;
+    int prim; // -1 = miss
+    int aux;  // box face
+};
+
+// Tests primitive `id` and keeps it if it beats `best` by (t, id).
+__device__ __forceinline__ void test_prim(const DevScene& S, int id, f3 o, f3 d, float maxd, Hit& best)
+{
+    float t; int aux = 0; bool h;
+    if (id < S.n_sph) {
+        h = hit_sphere(S.sph[id], o, d, maxd, t);
+    } else if (id < S.n_sph + S.n_box) {
+        const float4* b = S.box + 4 * (id - S.n_sph);
+        h = hit_box(b[0], b[1], b[2], b[3], o, d, maxd, t, aux);
+    } else {
+        const float4* tr = S.tri + 3 * (size_t)(id - S.n_sph - S.n_box);
+        h = hit_tri(xyz(tr[0]), xyz(tr[1]), xyz(tr[2]), o, d, maxd, t);
+    }
+    if (h && (t < best.t || (t == best.t && id < best.prim) || best.prim < 0)) {
+        best.t = t; best.prim = id; best.aux = aux;
+    }
+}
+
+// Brute force over all primitives in id order; primitive data is wave-uniform, so the loads
+// go through the scalar cache and the operands sit in SGPRs.
+template <bool ANY>
+__device__ __forceinline__ Hit intersect_brute(const DevScene& S, f3 o, f3 d, float maxd, int skip)
+{
+    Hit best; best.t = INFINITY; best.prim = -1; best.aux = 0;
+    if (is_zero3(d)) return best;
+    for (int i = 0; i < S.n_sph; ++i) {
+        float t;
+        if (i != skip && hit_sphere(S.sph[i], o, d, maxd, t) && t < best.t) {
+            best.t = t; best.prim = i;
+            if (ANY) return best;
+        }
+    }
+    for (int i = 0; i < S.n_box; ++i) {
+        float t; int aux;
+        const float4* b = S.box + 4 * i;
+        if (i + S.n_sph != skip && hit_box(b[0], b[1], b[2], b[3], o, d, maxd, t, aux) && t < best.t) {
+            best.t = t; best.prim = i + S.n_sph; best.aux = aux;
+            if (ANY) return best;
+        }
+    }
+    for (int i = 0; i < S.n_tri; ++i) {
+        float t;
+        const float4* tr = S.tri + 3 * (size_t)i;
+        if (i + S.n_sph + S.n_box != skip &&
+            hit_tri(xyz(tr[0]), xyz(tr[1]), xyz(tr[2]), o, d, maxd, t) && t < best.t) {
+            best.t = t; best.prim = i + S.n_sph + S.n_box;
+            if (ANY) return best;
+        }
+    }
+    return best;
+}
+
+// Conservative ray/box test for BVH nodes: NaNs from 0*inf are dropped by fminf/fmaxf and
+// the far side is widened by 2 ulp so rounding can only add candidates, never lose one.
+__device__ __forceinline__ bool slab_test(f3 lo, f3 hi, f3 o, f3 inv, float tmax, float& tnear)
+{
+    float ax = (lo.x - o.x) * inv.x, bx = (hi.x - o.x) * inv.x;
+    float ay = (lo.y - o.y) * inv.y, by = (hi.y - o.y) * inv.y;
+    float az = (lo.z - o.z) * inv.z, bz = (hi.z - o.z) * inv.z;
+    float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.f));
+    float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax));
+    tnear = t0;
+    return t0 <= t1 * 1.0000004f;
+}
+
+// Stack-based traversal of the 2-wide LBVH, nearer child first.  The result does not depend
+// on the traversal order because candidates are ranked by (t, id).
+template <bool ANY>
+__device__ __forceinline__ Hit intersect_bvh(const DevScene& S, f3 o, f3 d, float maxd, int skip)
+{
+    Hit best; best.t = INFINITY; best.prim = -1; best.aux = 0;
+    if (is_zero3(d)) return best;
+    f3 inv = mk3(1.f / d.x, 1.f / d.y, 1.f / d.z);
+    int stack[VRT_BVH_STACK];
+    int sp = 0;
+    int node = 0;
+    for (;;) {
+        const float4* n = S.bvh + 4 * (size_t)node;
+        float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
+        int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
+        float lim = best.prim >= 0 ? best.t : maxd;
+        float tn0, tn1;
+        bool h0 = slab_test(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), o, inv, lim, tn0);
+        bool h1 = slab_test(mk3(n1.z, n1.w, n2.x), mk3(n2.y, n2.z, n2.w), o, inv, lim, tn1);
+        if (h0 && c0 < 0) { if (~c0 != skip) test_prim(S, ~c0, o, d, maxd, best); h0 = false; }
+        if (h1 && c1 < 0) { if (~c1 != skip) test_prim(S, ~c1, o, d, maxd, best); h1 = false; }
+        if (ANY && best.prim >= 0) return best;
+        if (h0 && h1) {
+            int nearc = tn1 < tn0 ? c1 : c0, farc = tn1 < tn0 ? c0 : c1;
+            if (sp < VRT_BVH_STACK) stack[sp++] = farc;
+            node = nearc;
+        } else if (h0) {
+            node = c0;
+        } else if (h1) {
+            node = c1;
+        } else {
+            if (sp == 0) break;
+            node = stack[--sp];
+        }
+    }
+    return best;
+}
+
+template <bool BVH, bool ANY>
+__device__ __forceinline__ Hit intersect(const DevScene& S, f3 o, f3 d, float maxd, int skip)
+{
+    if (BVH) return intersect_bvh<ANY>(S, o, d, maxd, skip);
+    return intersect_brute<ANY>(S, o, d, maxd, skip);
+}
+
+// hit.point = origin + direction * distance; hit.normal per collider type.
+__device__ __forceinline__ void hit_geometry(const DevScene& S, Hit h, f3 o, f3 d, f3& point, f3& normal)
+{
+    point = o + d * h.t;
+    if (h.prim < S.n_sph) {
+        normal = normalize3(point - xyz(S.sph[h.prim]));
+    } else if (h.prim < S.n_sph + S.n_box) {
+        float4 a = S.box[4 * (h.prim - S.n_sph) + 1 + (h.aux & 3)];
+        float s = (h.aux & 4) ? 1.f : -1.f;
+        normal = xyz(a) * s;
+    } else {
+        const float4* tr = S.tri + 3 * (size_t)(h.prim - S.n_sph - S.n_box);
+        normal = normalize3(cross3(xyz(tr[1]), xyz(tr[2])));
+    }
+}
+
+// ------------------------------------------------------------------ recording / counting
+
+struct Counters { unsigned precheck, primary, reflect, transmit, shadow, ao; };
+
+struct Recorder {
+    vrt_path_seg* segs; // null = off
+    int cap;
+    int n;
+    int sample;
+};
+
+template <bool RECORD>
+__device__ __forceinline__ void record_seg(Recorder& R, f3 o, f3 d, Hit h, int kind, int depth, float range)
+{
+    if (!RECORD) return;
+    if (R.n < R.cap) {
+        vrt_path_seg* s = R.segs + R.n;
+        f3 e = o + d * (h.prim >= 0 ? h.t : range);
+        s->origin[0] = o.x; s->origin[1] = o.y; s->origin[2] = o.z;
+        s->end[0] = e.x; s->end[1] = e.y; s->end[2] = e.z;
+        s->kind = kind; s->depth = depth; s->hit_prim = h.prim; s->sample = R.sample;
+    }
+    R.n++;
+}
+
+// ------------------------------------------------------------------ shading
+
+// Util/RayTraceUtility.cs:123-131
+__device__ __forceinline__ f3 sky_color(f3 direction)
+{
+    f3 u = normalize3(direction);
+    float t = 0.5f * (u.y + 1.f);
+    f3 a = mk3(1.f, 1.f, 1.f) * (1.f - t);
+    f3 b = mk3(.5f, .7f, 1.f) * t;
+    return a + b;
+}
+
+// Light/AmbientOccluder.cs:56-85.  The reference builds u and v with Mathf.Pow of the normal's
+// components and shoots sp.x*u + sp.y*v + sp.z*w with the hemisphere sample sp = (0,0,1) (its
+// multi-jittered table is all zeros, Sampler/MultiJitteredSampler.cs:23-27,39).  A negative base
+// or Pow(0, negative) makes u or v NaN/Inf, 0*Inf poisons the direction, the Ray constructor
+// normalises it to zero and no ray is cast.  Working that through: the direction degenerates
+// iff n.x < 0 or n.z < 0 or (n.y < 0 and n.y != -1); otherwise it equals n.
+template <bool BVH, bool RECORD>
+__device__ __forceinline__ f3 ambient_L(const DevScene& S, const DevParams& P, f3 point, f3 n, int prim,
+                                        int depth, Counters& C, Recorder& R)
+{
+    bool cast = true;
+    if (!(P.flags & VRT_FIX_AO_BASIS))
+        cast = !(n.x < 0.f || n.z < 0.f || (n.y < 0.f && n.y != -1.f));
+    bool occluded = false;
+    if (cast) {
+        f3 dir = normalize3(mk3(n.x + 0.f, n.y + 0.f, n.z + 0.f));
+        if (!is_zero3(dir)) {
+            C.ao++;
+            Hit h = RECORD ? intersect<BVH, false>(S, point, dir, P.range, prim)
+                           : intersect<BVH, true>(S, point, dir, P.range, prim);
+            record_seg<RECORD>(R, point, dir, h, VRT_RAY_AO, depth, P.range);
+            occluded = h.prim >= 0;
+        }
+    }
+    const vrt_shading& sh = S.sh;
+    f3 lc = mk3(sh.ao_color[0], sh.ao_color[1], sh.ao_color[2]);
+    if (occluded) {
+        f3 mn = mk3(sh.ao_min_amount[0], sh.ao_min_amount[1], sh.ao_min_amount[2]);
+        return (mn * sh.ao_ls) * lc;
+    }
+    return lc * sh.ao_ls;
+}
+
+// Material/PhongMaterial.cs:53-89 with BRDF/LambertianBRDF.cs:23-26,54-57,
+// BRDF/GlossySpecularBRDF.cs:40-63, Light/PointLight.cs:23-51, Light/DirectionalLight.cs:22-42.
+template <bool BVH, bool RECORD>
+__device__ __forceinline__ f3 phong_shade(const DevScene& S, const DevParams& P, f3 point, f3 n, int prim,
+                                          f3 raydir, int depth, float ka, float kd, float ks, float ex,
+                                          f3 cd, Counters& C, Recorder& R)
+{
+    f3 wo = -raydir;
+    f3 L = (cd * ka) * ambient_L<BVH, RECORD>(S, P, point, n, prim, depth, C, R);
+    for (int i = 0; i < S.n_lights; ++i) {
+        const DevLight& l = S.lights[i];
+        f3 lp = mk3(l.vx, l.vy, l.vz);
+        f3 wi;
+        if (l.type == VRT_LIGHT_POINT) {
+            f3 tmp = lp - point;
+            float len = sqrtf(tmp.x * tmp.x + tmp.y * tmp.y + tmp.z * tmp.z);
+            wi = mk3(tmp.x / len, tmp.y / len, tmp.z / len);
+        } else {
+            wi = lp;
+        }
+        float ndotwi = dot3(n, wi);
+        if (ndotwi > 0.f) {
+            bool in_shadow = false;
+            if (l.cast) {
+                f3 sd = normalize3(wi);
+                f3 loc = l.type == VRT_LIGHT_POINT ? lp : mk3(l.lx, l.ly, l.lz);
+                float dist = mag3(loc - point);
+                if (!is_zero3(sd)) {
+                    C.shadow++;
+                    Hit h = intersect<BVH, false>(S, point, sd, 30.f, prim);
+                    record_seg<RECORD>(R, point, sd, h, VRT_RAY_SHADOW, depth, 30.f);
+                    if (h.prim >= 0) in_shadow = h.t < dist;
+                }
+            }
+            if (!in_shadow) {
+                f3 diff = (cd * kd) * 0.3183098861837906715f;
+                float nda = dot3(n, wo);
+                f3 r = mk3(-wo.x + 2.f * n.x * nda, -wo.y + 2.f * n.y * nda, -wo.z + 2.f * n.z * nda);
+                float rdb = dot3(r, wi);
+                float spec = 0.f;
+                if (rdb > 0.f) spec = (1.f * ks) * powf(rdb, ex);
+                f3 lam = mk3(diff.x + spec, diff.y + spec, diff.z + spec);
+                f3 world = (mk3(l.cr, l.cg, l.cb) * l.ls) * ndotwi;
+                L = L + lam * world;
+            }
+        }
+    }
+    return L;
+}
+
+// BRDF/FresnelReflectorBRDF.cs:14-39 (only with VRT_FIX_DIELECTRIC)
+__device__ __forceinline__ float fresnel_kr(f3 normal, f3 direction, float eta_in, float eta_out)
+{
+    float ndotd = dot3(-normal, direction);
+    float eta;
+    if (ndotd < 0.f) { normal = -normal; eta = eta_out / eta_in; }
+    else eta = eta_in / eta_out;
+    float ci = dot3(-normal, direction);
+    float ct = sqrtf(1.f - (1.f - ci * ci) / (eta * eta));
+    float rpar = (eta * ci - ct) / (eta * ci + ct);
+    float rper = (ci - eta * ct) / (ci + eta * ct);
+    return 0.5f * (rpar * rpar + rper * rper);
+}
+
+// One surface interaction: direct lighting A and up to two child rays with their weights.
+struct Bounce {
+    f3 A;         // Phong term of this hit
+    int n_child;  // 0, 1 or 2
+    f3 o;         // child origin = hit point
+    f3 d0, w0;    // first child (reflection): unit direction, weight
+    f3 d1, w1;    // second child (transmission)
+    int prim;
+};
+
+// Tracer/WhittedTracer.cs:49-88 (material dispatch) + Material/ReflectiveMaterial.cs:25-42 +
+// Material/DielectricMaterial.cs:56-146 + BRDF/PerfectSpecularBRDF.cs:29-39.
+template <bool BVH, bool RECORD>
+__device__ __forceinline__ void shade_hit(const DevScene& S, const DevParams& P, Hit h, f3 o, f3 d, int depth,
+                                          Counters& C, Recorder& R, Bounce& B)
+{
+    f3 point, n;
+    hit_geometry(S, h, o, d, point, n);
+    float4 m = S.mat[S.prim_mat[h.prim]];
+    int mtype = __float_as_int(m.w);
+    f3 cd = mk3(m.x, m.y, m.z);
+    const vrt_shading& sh = S.sh;
+    B.prim = h.prim; B.o = point; B.n_child = 0;
+    if (mtype == VRT_MAT_METAL) {
+        B.A = phong_shade<BVH, RECORD>(S, P, point, n, h.prim, d, depth, sh.metal_ka, sh.metal_kd,
+                                       sh.metal_ks, sh.metal_exp, cd, C, R);
+        f3 wo = -d;
+        float ndotwo = dot3(n, wo);
+        f3 wi = (-wo) + (n * 2.f) * ndotwo;
+        float nd = dot3(n, wi);
+        f3 fr = (mk3(sh.metal_cr[0], sh.metal_cr[1], sh.metal_cr[2]) * sh.metal_kr) / fabsf(nd);
+        B.n_child = 1; B.d0 = normalize3(wi); B.w0 = fr * nd;
+    } else if (mtype == VRT_MAT_DIELECTRIC) {
+        B.A = phong_shade<BVH, RECORD>(S, P, point, n, h.prim, d, depth, sh.glass_ka, sh.glass_kd,
+                                       sh.glass_ks, sh.glass_exp, cd, C, R);
+        f3 wo = -d;
+        float ndotwo = dot3(n, wo);
+        f3 wi = (-wo) + (n * 2.f) * ndotwo;
+        B.n_child = 1; B.d0 = normalize3(wi); B.w0 = mk3(1.f, 1.f, 1.f);
+        if (P.flags & VRT_FIX_DIELECTRIC) {
+            float eta = sh.glass_eta_in / sh.glass_eta_out;
+            float ci = dot3(n, wo);
+            f3 nn = n;
+            if (ci < 0.f) { ci = -ci; nn = -n; eta = 1.f / eta; }
+            float temp = 1.f - (1.f - ci * ci) / (eta * eta);
+            if (!(temp < 0.f)) {
+                float kr = fresnel_kr(n, d, sh.glass_eta_in, sh.glass_eta_out);
+                float kt = 1.f - kr;
+                float c2 = sqrtf(temp);
+                f3 wt = ((-wo) / eta) - nn * (c2 - ci / eta);
+                float ndotwi = dot3(n, wi), ndotwt = dot3(n, wt);
+                float wr = (kr / fabsf(ndotwi)) * fabsf(ndotwi);
+                float wtt = (kt / (eta * eta) / fabsf(ndotwt)) * fabsf(ndotwt);
+                B.w0 = mk3(wr, wr, wr);
+                B.n_child = 2; B.d1 = normalize3(wt); B.w1 = mk3(wtt, wtt, wtt);
+            }
+        }
+    } else {
+        B.A = phong_shade<BVH, RECORD>(S, P, point, n, h.prim, d, depth, sh.solid_ka, sh.solid_kd,
+                                       sh.solid_ks, sh.solid_exp, cd, C, R);
+    }
+}
+
+// RayTracerUnity.cs:486-517 + AntiAliasingStrategy.cs:89-90
+__device__ __forceinline__ f3 camera_raw_dir(const DevCam& cam, int h, int v)
+{
+    float hScale = (float)v / (float)cam.width;
+    float vScale = (float)h / (float)cam.height;
+    f3 ho = mk3(cam.xx, cam.xy, cam.xz) * hScale;
+    f3 vo = mk3(cam.yx, cam.yy, cam.yz) * vScale;
+    return (mk3(cam.bx, cam.by, cam.bz) + ho) + vo;
+}
+
+// Util/RayTraceUtility.cs:409-422 through RayTracerUnity.cs:525-562 (the gamma step there is
+// computed on a local and dropped).
+__device__ __forceinline__ float4 process_color(f3 c)
+{
+    float m = fmaxf(c.x, fmaxf(c.y, c.z));
+    if (m > 1.f) return make_float4(c.x / m, c.y / m, c.z / m, 1.f / m);
+    return make_float4(c.x, c.y, c.z, 1.f);
+}
+
+struct PendingRay { f3 o, d, T; int depth, skip, kind; };
+
+// Tracer/WhittedTracer.cs:33-104 as an iterative loop: radiance is accumulated as
+// sum(throughput * direct term) instead of unwinding a recursion; the second child of a
+// refracting hit waits on a bounded per-lane stack.
+template <bool BVH, bool RECORD, bool TWOCHILD>
+__device__ __forceinline__ f3 trace_path(const DevScene& S, const DevParams& P, f3 o, f3 d, Hit first,
+                                         Counters& C, Recorder& R)
+{
+    f3 L = mk3(0.f, 0.f, 0.f);
+    f3 T = mk3(1.f, 1.f, 1.f);
+    int depth = 0, skip = -1, kind = VRT_RAY_PRIMARY;
+    Hit h = first;
+    bool have_first = true;
+    PendingRay stack[TWOCHILD ? VRT_MAX_DEPTH + 2 : 1];
+    int sp = 0;
+    for (;;) {
+        if (!have_first) {
+            h.prim = -1; h.t = INFINITY; h.aux = 0;
+            if (!is_zero3(d)) {
+                if (kind == VRT_RAY_REFLECT) C.reflect++; else C.transmit++;
+                h = intersect<BVH, false>(S, o, d, P.range, skip);
+                record_seg<RECORD>(R, o, d, h, kind, depth, P.range);
+            }
+        }
+        have_first = false;
+        bool cont = false;
+        if (h.prim < 0) {
+            L = L + T * sky_color(d);
+        } else {
+            Bounce B;
+            shade_hit<BVH, RECORD>(S, P, h, o, d, depth, C, R, B);
+            L = L + T * B.A;
+            if (B.n_child > 0 && depth + 1 <= P.max_depth) {
+                if (TWOCHILD && B.n_child == 2 && sp < VRT_MAX_DEPTH + 2) {
+                    PendingRay& q = stack[sp++];
+                    q.o = B.o; q.d = B.d1; q.T = T * B.w1; q.depth = depth + 1; q.skip = B.prim;
+                    q.kind = VRT_RAY_TRANSMIT;
+                }
+                o = B.o; d = B.d0; T = T * B.w0; depth = depth + 1; skip = B.prim; kind = VRT_RAY_REFLECT;
+                cont = true;
+            }
+        }
+        if (!cont) {
+            if (!TWOCHILD || sp == 0) break;
+            PendingRay& q = stack[--sp];
+            o = q.o; d = q.d; T = q.T; depth = q.depth; skip = q.skip; kind = q.kind;
+        }
+    }
+    return L;
+}
+
+// RayTracerUnity.cs:565-597: all samples of one pixel, averaged and tone-mapped.
+// sample_sel < 0: every sample; otherwise just that one (single-step mode).
+template <bool BVH, bool RECORD, bool TWOCHILD>
+__device__ __forceinline__ float4 trace_pixel_dev(const DevScene& S, const DevCam& cam, const DevParams& P,
+                                                  int h, int v, int sample_sel, int& hit_id,
+                                                  Counters& C, Recorder& R)
+{
+    f3 O = mk3(cam.ox, cam.oy, cam.oz);
+    f3 raw = camera_raw_dir(cam, h, v);
+    unsigned pixel = (unsigned)(h * cam.width + v);
+    unsigned set = pixel_set_dev(P.seed, pixel, (unsigned)P.n_sets);
+    const float2* off = P.offsets ? P.offsets + (size_t)set * P.spp : nullptr;
+    f3 sum = mk3(0.f, 0.f, 0.f);
+    hit_id = -1;
+    int i0 = sample_sel < 0 ? 0 : sample_sel, i1 = sample_sel < 0 ? P.spp : sample_sel + 1;
+    for (int i = i0; i < i1; ++i) {
+        float ox = 0.f, oy = 0.f;
+        if (off) { float2 q = off[i]; ox = q.x; oy = q.y; }
+        f3 d = normalize3(mk3(raw.x + ox, raw.y + oy, raw.z));
+        R.sample = i;
+        Hit first; first.prim = -1; first.t = INFINITY; first.aux = 0;
+        if (!is_zero3(d)) {
+            // one closest-hit query answers both the any-hit pre-check (RayTracerUnity.cs:582)
+            // and the primary TraceRay (:584); they are counted as the two queries they replace
+            C.precheck++;
+            first = intersect<BVH, false>(S, O, d, P.range, -1);
+        }
+        if (i == 0) hit_id = first.prim;
+        if (first.prim >= 0) {
+            C.primary++;
+            record_seg<RECORD>(R, O, d, first, VRT_RAY_PRIMARY, 0, P.range);
+            sum = sum + trace_path<BVH, RECORD, TWOCHILD>(S, P, O, d, first, C, R);
+        } else if (P.flags & VRT_FIX_PRIMARY_SKY) {
+            sum = sum + sky_color(d);
+        }
+    }
+    f3 fin = sum / (float)(i1 - i0);
+    return process_color(fin);
+}

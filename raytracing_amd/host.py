@@ -1,0 +1,154 @@
+"""ctypes binding of libvrt.so — the only route from Python to the HIP kernels.
+
+There is no CPU fallback: if the library is missing or no GPU is present the calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libvrt.so")
+_lib = None
+
+
+class VrtError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libvrt error {code}: {msg}")
+        self.code = code
+
+
+def library_path():
+    return _LIB_PATH
+
+
+def load_library():
+    """Loads raytracing_amd/libvrt.so (built by `make -C raytracing_amd/csrc` or
+    __graft_entry__.build()).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise RuntimeError(f"{_LIB_PATH} is missing: build it with __graft_entry__.build(); "
+                           "there is no CPU fallback")
+    L = C.CDLL(_LIB_PATH)
+    vp = C.c_void_p
+    L.vrt_abi_version.restype = C.c_int
+    L.vrt_create.restype = C.c_int
+    L.vrt_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.vrt_destroy.restype = C.c_int
+    L.vrt_destroy.argtypes = [vp]
+    L.vrt_last_error.restype = C.c_char_p
+    L.vrt_last_error.argtypes = [vp]
+    L.vrt_shading_defaults.restype = None
+    L.vrt_shading_defaults.argtypes = [C.POINTER(abi.vrt_shading)]
+    L.vrt_params_defaults.restype = None
+    L.vrt_params_defaults.argtypes = [C.POINTER(abi.vrt_params)]
+    L.vrt_set_scene.restype = C.c_int
+    L.vrt_set_scene.argtypes = [vp, C.POINTER(abi.vrt_scene_desc)]
+    L.vrt_set_camera.restype = C.c_int
+    L.vrt_set_camera.argtypes = [vp, C.POINTER(abi.vrt_camera)]
+    L.vrt_render.restype = C.c_int
+    L.vrt_render.argtypes = [vp, C.POINTER(abi.vrt_params), vp, vp, C.POINTER(abi.vrt_stats)]
+    L.vrt_render_device.restype = C.c_int
+    L.vrt_render_device.argtypes = [vp, C.POINTER(abi.vrt_params), vp, vp, vp]
+    L.vrt_fetch_stats.restype = C.c_int
+    L.vrt_fetch_stats.argtypes = [vp, C.POINTER(abi.vrt_stats)]
+    L.vrt_trace_pixel.restype = C.c_int
+    L.vrt_trace_pixel.argtypes = [vp, C.POINTER(abi.vrt_params), C.c_int, C.c_int, C.c_int,
+                                  C.POINTER(abi.vrt_path_seg), C.c_int, C.POINTER(C.c_int),
+                                  C.POINTER(C.c_float), C.POINTER(C.c_int32)]
+    L.vrt_sampler_table.restype = C.c_int
+    L.vrt_sampler_table.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_uint64, vp]
+    L.vrt_pixel_set.restype = C.c_uint32
+    L.vrt_pixel_set.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
+    if L.vrt_abi_version() != abi.VRT_ABI_VERSION:
+        raise RuntimeError("libvrt.so ABI version mismatch; rebuild it")
+    _lib = L
+    return L
+
+
+def sampler_table(sampler, n_samples, n_sets, h_step, v_step, seed=0):
+    """AntiAliasingStrategy's sampler table in access order, shape (n_sets, n_samples, 2)."""
+    out = np.zeros((n_sets, n_samples, 2), np.float32)
+    rc = load_library().vrt_sampler_table(sampler, n_samples, n_sets, h_step, v_step, seed,
+                                          out.ctypes.data)
+    if rc != 0:
+        raise VrtError(rc, "vrt_sampler_table: invalid arguments")
+    return out
+
+
+def pixel_set(seed, pixel, n_sets):
+    return load_library().vrt_pixel_set(seed, pixel, n_sets)
+
+
+class Context:
+    """One vrt_ctx on one GPU."""
+
+    def __init__(self, device=0):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        rc = self._lib.vrt_create(device, C.byref(self._h))
+        if rc != 0:
+            self._h = None
+            raise VrtError(rc, "vrt_create failed (no usable HIP device?)")
+        self.device = device
+        self._scene = None
+        self.cam = None
+
+    def close(self):
+        if self._h:
+            self._lib.vrt_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise VrtError(rc, self._lib.vrt_last_error(self._h).decode())
+
+    def set_scene(self, scene):
+        d = scene.desc()
+        self._chk(self._lib.vrt_set_scene(self._h, C.byref(d)))
+        self._scene = scene
+
+    def set_camera(self, cam):
+        self._chk(self._lib.vrt_set_camera(self._h, C.byref(cam)))
+        self.cam = cam
+
+    def render(self, params, rgba=None, hit=None):
+        """Whole frame into host arrays. Returns (rgba[H,W,4], hit[H,W], vrt_stats)."""
+        H, W = self.cam.height, self.cam.width
+        if rgba is None:
+            rgba = np.zeros((H, W, 4), np.float32)
+        if hit is None:
+            hit = np.full((H, W), -1, np.int32)
+        st = abi.vrt_stats()
+        self._chk(self._lib.vrt_render(self._h, C.byref(params.c), rgba.ctypes.data,
+                                       hit.ctypes.data, C.byref(st)))
+        return rgba, hit, st
+
+    def render_device(self, params, rgba_ptr, hit_ptr=None, stream=None):
+        """Enqueues a frame whose outputs stay in device memory (raw device pointers)."""
+        self._chk(self._lib.vrt_render_device(self._h, C.byref(params.c), rgba_ptr, hit_ptr,
+                                              stream))
+
+    def fetch_stats(self):
+        st = abi.vrt_stats()
+        self._chk(self._lib.vrt_fetch_stats(self._h, C.byref(st)))
+        return st
+
+    def trace_pixel(self, params, h, v, sample=-1, cap=256):
+        segs = (abi.vrt_path_seg * max(cap, 1))()
+        n = C.c_int(0)
+        rgba = (C.c_float * 4)()
+        hit = C.c_int32(-1)
+        self._chk(self._lib.vrt_trace_pixel(self._h, C.byref(params.c), h, v, sample,
+                                            segs if cap > 0 else None, cap, C.byref(n), rgba,
+                                            C.byref(hit)))
+        return np.array(rgba[:], np.float32), hit.value, segs, n.value

@@ -1,0 +1,114 @@
+"""GPU parity on the teaching scene: libvrt through its C ABI vs the CPU oracle."""
+import numpy as np
+import pytest
+
+import raytracing_amd as ra
+from raytracing_amd import abi, host
+
+pytestmark = pytest.mark.gpu
+
+RGB_TOL = 1.0 / 255.0  # the tolerance the benchmark definition states for RGB
+
+
+def _compare(ctx, oracle_mod, scene, cam, prm, exact_hits=True):
+    ctx.set_scene(scene)
+    ctx.set_camera(cam)
+    rgba, hit, st = ctx.render(prm)
+    o_rgba, o_hit, o_rays = oracle_mod.render(scene, cam, prm.c, n_threads=8)
+    if exact_hits:
+        assert np.array_equal(hit, o_hit)
+    assert np.array_equal(np.array(st.rays[:], np.uint64), o_rays)
+    both_nan = np.isnan(rgba) & np.isnan(o_rgba)
+    err = np.abs(np.where(both_nan, 0, rgba) - np.where(both_nan, 0, o_rgba))
+    assert np.nanmax(err) <= RGB_TOL, np.nanmax(err)
+    assert not np.isnan(err).any()
+    return rgba, hit, st
+
+
+def test_teaching_scene_1spp(vrt_ctx, oracle_mod):
+    _compare(vrt_ctx, oracle_mod, ra.teaching_scene(), ra.teaching_camera(320, 180),
+             ra.Params(spp=1, max_depth=5))
+
+
+def test_teaching_scene_shipped_config(vrt_ctx, oracle_mod):
+    """200x200, Hammersley 50 spp x 83 sets, depth 10 (VisualRayTrace.unity:13859-13873)."""
+    offs = host.sampler_table(abi.VRT_SAMPLER_HAMMERSLEY, 50, 83, 0.01, 0.005, seed=1)
+    _compare(vrt_ctx, oracle_mod, ra.teaching_scene(point_light=False), ra.teaching_camera(200, 200),
+             ra.Params(spp=50, offsets=offs, seed=11, max_depth=10))
+
+
+@pytest.mark.parametrize("sampler", [abi.VRT_SAMPLER_REGULAR, abi.VRT_SAMPLER_RANDOM,
+                                     abi.VRT_SAMPLER_JITTERED, abi.VRT_SAMPLER_NROOKS,
+                                     abi.VRT_SAMPLER_MULTIJITTERED])
+def test_samplers(vrt_ctx, oracle_mod, sampler):
+    offs = host.sampler_table(sampler, 9, 5, 0.02, 0.01, seed=sampler + 1)
+    _compare(vrt_ctx, oracle_mod, ra.teaching_scene(), ra.teaching_camera(96, 96),
+             ra.Params(spp=9, offsets=offs, seed=5, max_depth=3))
+
+
+@pytest.mark.parametrize("flags", [abi.VRT_FIX_PRIMARY_SKY, abi.VRT_FIX_AO_BASIS,
+                                   abi.VRT_FIX_DIELECTRIC,
+                                   abi.VRT_FIX_PRIMARY_SKY | abi.VRT_FIX_AO_BASIS | abi.VRT_FIX_DIELECTRIC])
+def test_fix_flags(vrt_ctx, oracle_mod, flags):
+    _compare(vrt_ctx, oracle_mod, ra.teaching_scene(), ra.teaching_camera(160, 90),
+             ra.Params(spp=1, max_depth=6, flags=flags))
+
+
+def test_depth_zero_and_ragged_frame(vrt_ctx, oracle_mod):
+    _compare(vrt_ctx, oracle_mod, ra.teaching_scene(), ra.teaching_camera(37, 13),
+             ra.Params(spp=1, max_depth=0))
+
+
+def test_tile_sharding_matches_whole_frame(vrt_ctx, oracle_mod):
+    scene, cam = ra.teaching_scene(), ra.teaching_camera(64, 50)
+    vrt_ctx.set_scene(scene)
+    vrt_ctx.set_camera(cam)
+    whole, whole_hit, _ = vrt_ctx.render(ra.Params(spp=1, max_depth=4))
+    rgba = np.zeros_like(whole)
+    hit = np.full_like(whole_hit, -7)
+    total = 0
+    for k in range(3):
+        _, _, st = vrt_ctx.render(ra.Params(spp=1, max_depth=4, tile_index=k, tile_count=3, tile_rows=8),
+                                  rgba=rgba, hit=hit)
+        total += st.pixels
+    assert total == 64 * 50
+    assert np.array_equal(rgba, whole, equal_nan=True)
+    assert np.array_equal(hit, whole_hit)
+
+
+def test_trace_pixel_and_records(vrt_ctx, oracle_mod):
+    scene, cam = ra.teaching_scene(), ra.teaching_camera(160, 90)
+    vrt_ctx.set_scene(scene)
+    vrt_ctx.set_camera(cam)
+    prm = ra.Params(spp=1, max_depth=5)
+    frame, fhit, _ = vrt_ctx.render(prm)
+    for (h, v) in [(45, 60), (30, 100), (10, 10), (80, 150), (44, 85)]:
+        rgba, hit, segs, n = vrt_ctx.trace_pixel(prm, h, v, sample=-1, cap=64)
+        o_rgba, o_hit, o_segs, o_n, _ = oracle_mod.trace_pixel(scene, cam, prm.c, h, v, -1, 64)
+        assert hit == o_hit == fhit[h, v]
+        assert np.array_equal(rgba, frame[h, v], equal_nan=True)
+        assert n == o_n
+        for i in range(min(n, 64)):
+            a, b = segs[i], o_segs[i]
+            assert (a.kind, a.depth, a.hit_prim, a.sample) == (b.kind, b.depth, b.hit_prim, b.sample)
+            assert list(a.origin) == list(b.origin)
+            assert list(a.end) == list(b.end)
+
+
+def test_error_paths(vrt_ctx):
+    scene, cam = ra.teaching_scene(), ra.teaching_camera(16, 16)
+    vrt_ctx.set_scene(scene)
+    vrt_ctx.set_camera(cam)
+    with pytest.raises(host.VrtError) as e:
+        vrt_ctx.render(ra.Params(spp=0))
+    assert e.value.code == abi.VRT_ERR_INVALID
+    with pytest.raises(host.VrtError) as e:
+        vrt_ctx.render(ra.Params(spp=1, max_depth=99))
+    assert e.value.code == abi.VRT_ERR_CAPACITY
+    with pytest.raises(host.VrtError):
+        vrt_ctx.trace_pixel(ra.Params(spp=1), 16, 0)
+    bad = ra.teaching_scene()
+    bad.spheres["material"][0] = 99
+    with pytest.raises(host.VrtError):
+        vrt_ctx.set_scene(bad)
+    vrt_ctx.set_scene(scene)
