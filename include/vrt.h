@@ -189,6 +189,8 @@ typedef struct vrt_params {
     int32_t tile_index;
     int32_t tile_count;   /* <= 1: whole frame */
     int32_t tile_rows;
+    int32_t compact_rows; /* != 0: the output buffers hold only this call's rows, packed in
+                             ascending row order (local_rows * width entries) */
     /* Path recording for a bounded set of pixels (linear index h*width+v). */
     int32_t n_record_pixels;
     const int32_t* record_pixels;

@@ -86,6 +86,7 @@ class vrt_params(C.Structure):
                 ("seed", C.c_uint32), ("max_depth", C.c_int32), ("range", C.c_float),
                 ("flags", C.c_uint32), ("mode", C.c_int32),
                 ("tile_index", C.c_int32), ("tile_count", C.c_int32), ("tile_rows", C.c_int32),
+                ("compact_rows", C.c_int32),
                 ("n_record_pixels", C.c_int32), ("record_pixels", C.POINTER(C.c_int32)),
                 ("record_cap", C.c_int32), ("record_out", C.POINTER(vrt_path_seg)),
                 ("record_count_out", C.POINTER(C.c_int32))]

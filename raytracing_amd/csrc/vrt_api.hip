@@ -283,6 +283,7 @@ static int prepare(vrt_ctx* c, const vrt_params* p, DevParams* out)
     P.tile_index = tcount > 1 ? p->tile_index : 0; P.tile_count = tcount;
     P.tile_rows = p->tile_rows > 0 ? p->tile_rows : 8;
     P.local_rows = owned_rows(c->cam.height, P.tile_index, tcount, P.tile_rows);
+    P.compact = p->compact_rows != 0;
     P.offsets = nullptr;
     if (p->offsets) {
         size_t n = (size_t)p->n_sets * p->spp;
@@ -352,6 +353,13 @@ static int read_stats(vrt_ctx* c, vrt_stats* s)
     s->bvh_nodes = c->use_bvh ? (uint32_t)(c->scene.n_prims - 1) : 0;
     s->mode_used = c->last_mode;
     s->gpu_ms = 0.f;
+    if (c->last_mode == VRT_MODE_WAVEFRONT && c->wf.counts) {
+        int overflow = 0;
+        HIPCHK(c, hipMemcpy(&overflow, c->wf.counts + VRT_MAX_DEPTH + 2, sizeof(int), hipMemcpyDeviceToHost));
+        if (overflow)
+            return fail(c, VRT_ERR_CAPACITY, "wavefront ray queue overflowed (two-child refraction); "
+                                             "use VRT_MODE_MEGAKERNEL for this scene");
+    }
     if (c->timed) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) s->gpu_ms = ms;
@@ -409,7 +417,8 @@ extern "C" int vrt_render(vrt_ctx* c, const vrt_params* p, float* rgba_out, int3
         HIPCHK(c, hipMalloc(&c->d_hit, npix * sizeof(int)));
         c->fb_cap = npix;
     }
-    if (P.tile_count > 1) { // rows of other ranks stay as the caller left them
+    size_t nout = P.compact ? (size_t)P.local_rows * c->cam.width : npix;
+    if (P.tile_count > 1 && !P.compact) { // rows of other ranks stay as the caller left them
         HIPCHK(c, hipMemcpyAsync(c->d_rgba, rgba_out, npix * sizeof(float4), hipMemcpyHostToDevice, c->stream));
         if (hit_id_out)
             HIPCHK(c, hipMemcpyAsync(c->d_hit, hit_id_out, npix * sizeof(int), hipMemcpyHostToDevice, c->stream));
@@ -419,9 +428,9 @@ extern "C" int vrt_render(vrt_ctx* c, const vrt_params* p, float* rgba_out, int3
     if (rc) return rc;
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));
     c->timed = true;
-    HIPCHK(c, hipMemcpyAsync(rgba_out, c->d_rgba, npix * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(rgba_out, c->d_rgba, nout * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
     if (hit_id_out)
-        HIPCHK(c, hipMemcpyAsync(hit_id_out, c->d_hit, npix * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(hit_id_out, c->d_hit, nout * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (stats_out) { rc = read_stats(c, stats_out); if (rc) return rc; }
     if (p->n_record_pixels > 0) {

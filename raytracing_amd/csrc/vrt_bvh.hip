@@ -1,2 +1,270 @@
+// LBVH construction on the device (gfx950): Morton codes of primitive centroids -> radix sort
+// -> Karras' binary radix tree -> bottom-up fit of child boxes.  The output is the 64-byte
+// "two child boxes per node" layout described in vrt_device.h.
+//
+// Closest-hit results do not depend on the tree (candidates are ranked by (t, id)), so the
+// builder only has to be conservative: primitive boxes are padded by a relative 1e-4.
+#include <hip/hip_runtime.h>
+#include <cstring>
+#include <rocprim/rocprim.hpp>
+
 #include "vrt_launch.h"
-hipError_t vrt_build_lbvh(const DevScene&, float4*, int*, float*, hipStream_t) { return hipErrorNotSupported; }
+
+namespace {
+
+__device__ __forceinline__ unsigned enc_f(float f)
+{
+    unsigned b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__host__ __device__ inline float dec_f(unsigned e)
+{
+    unsigned b = (e & 0x80000000u) ? (e & 0x7fffffffu) : ~e;
+    float f;
+#ifdef __HIP_DEVICE_COMPILE__
+    f = __uint_as_float(b);
+#else
+    memcpy(&f, &b, 4);
+#endif
+    return f;
+}
+
+__device__ __forceinline__ void prim_box(const DevScene& S, int id, float lo[3], float hi[3])
+{
+    if (id < S.n_sph) {
+        float4 s = S.sph[id];
+        lo[0] = s.x - s.w; lo[1] = s.y - s.w; lo[2] = s.z - s.w;
+        hi[0] = s.x + s.w; hi[1] = s.y + s.w; hi[2] = s.z + s.w;
+    } else if (id < S.n_sph + S.n_box) {
+        const float4* b = S.box + 4 * (id - S.n_sph);
+        float4 b0 = b[0], b1 = b[1], b2 = b[2], b3 = b[3];
+        float c[3] = {b0.x, b0.y, b0.z};
+        float a0[3] = {b1.x, b1.y, b1.z}, a1[3] = {b2.x, b2.y, b2.z}, a2[3] = {b3.x, b3.y, b3.z};
+        for (int k = 0; k < 3; ++k) {
+            float e = fabsf(a0[k]) * b0.w + fabsf(a1[k]) * b1.w + fabsf(a2[k]) * b2.w;
+            lo[k] = c[k] - e; hi[k] = c[k] + e;
+        }
+    } else {
+        const float4* t = S.tri + 3 * (size_t)(id - S.n_sph - S.n_box);
+        float4 v0 = t[0], e1 = t[1], e2 = t[2];
+        float p0[3] = {v0.x, v0.y, v0.z};
+        float p1[3] = {v0.x + e1.x, v0.y + e1.y, v0.z + e1.z};
+        float p2[3] = {v0.x + e2.x, v0.y + e2.y, v0.z + e2.z};
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = fminf(p0[k], fminf(p1[k], p2[k]));
+            hi[k] = fmaxf(p0[k], fmaxf(p1[k], p2[k]));
+        }
+    }
+    for (int k = 0; k < 3; ++k) {
+        float e = 1e-4f * (1.f + fmaxf(fabsf(lo[k]), fabsf(hi[k])));
+        lo[k] -= e; hi[k] += e;
+    }
+}
+
+// Primitive boxes and the bounds of their centroids (6 ordered-uint atomics per block).
+__global__ __launch_bounds__(256) void k_prim_bounds(DevScene S, float4* __restrict__ pbox, unsigned* __restrict__ cb)
+{
+    __shared__ unsigned s_mn[3], s_mx[3];
+    if (threadIdx.x < 3) { s_mn[threadIdx.x] = 0xffffffffu; s_mx[threadIdx.x] = 0u; }
+    __syncthreads();
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < S.n_prims) {
+        float lo[3], hi[3];
+        prim_box(S, i, lo, hi);
+        pbox[2 * (size_t)i] = make_float4(lo[0], lo[1], lo[2], 0.f);
+        pbox[2 * (size_t)i + 1] = make_float4(hi[0], hi[1], hi[2], 0.f);
+        for (int k = 0; k < 3; ++k) {
+            unsigned e = enc_f(0.5f * (lo[k] + hi[k]));
+            atomicMin(&s_mn[k], e);
+            atomicMax(&s_mx[k], e);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        atomicMin(&cb[threadIdx.x], s_mn[threadIdx.x]);
+        atomicMax(&cb[3 + threadIdx.x], s_mx[threadIdx.x]);
+    }
+}
+
+__device__ __forceinline__ unsigned long long spread21(unsigned long long v)
+{
+    v &= 0x1fffffull;
+    v = (v | v << 32) & 0x1f00000000ffffull;
+    v = (v | v << 16) & 0x1f0000ff0000ffull;
+    v = (v | v << 8) & 0x100f00f00f00f00full;
+    v = (v | v << 4) & 0x10c30c30c30c30c3ull;
+    v = (v | v << 2) & 0x1249249249249249ull;
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_morton(int n, const float4* __restrict__ pbox, const unsigned* __restrict__ cb,
+                                                unsigned long long* __restrict__ keys, unsigned* __restrict__ vals)
+{
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float4 lo = pbox[2 * (size_t)i], hi = pbox[2 * (size_t)i + 1];
+    float c[3] = {0.5f * (lo.x + hi.x), 0.5f * (lo.y + hi.y), 0.5f * (lo.z + hi.z)};
+    unsigned long long code = 0;
+    for (int k = 0; k < 3; ++k) {
+        float mn = dec_f(cb[k]), mx = dec_f(cb[3 + k]);
+        float ext = mx - mn;
+        float u = ext > 0.f ? (c[k] - mn) / ext : 0.f;
+        u = fminf(fmaxf(u, 0.f), 1.f);
+        unsigned long long q = (unsigned long long)(u * 2097151.f);
+        code |= spread21(q) << (2 - k);
+    }
+    keys[i] = code;
+    vals[i] = (unsigned)i;
+}
+
+__device__ __forceinline__ int delta(const unsigned long long* __restrict__ keys, int n, int i, int j)
+{
+    if (j < 0 || j >= n) return -1;
+    unsigned long long a = keys[i], b = keys[j];
+    if (a == b) return 64 + __clz((unsigned)(i ^ j));
+    return __clzll((long long)(a ^ b));
+}
+
+// Karras 2012, one lane per internal node.  Children are stored as: >= 0 internal node index,
+// < 0 leaf with ~(sorted position).
+__global__ __launch_bounds__(256) void k_hierarchy(int n, const unsigned long long* __restrict__ keys,
+                                                   int2* __restrict__ child, int* __restrict__ parent,
+                                                   int* __restrict__ leaf_parent)
+{
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n - 1) return;
+    int d = delta(keys, n, i, i + 1) - delta(keys, n, i, i - 1) >= 0 ? 1 : -1;
+    int dmin = delta(keys, n, i, i - d);
+    int lmax = 2;
+    while (delta(keys, n, i, i + lmax * d) > dmin) lmax *= 2;
+    int l = 0;
+    for (int t = lmax / 2; t >= 1; t /= 2)
+        if (delta(keys, n, i, i + (l + t) * d) > dmin) l += t;
+    int j = i + l * d;
+    int dnode = delta(keys, n, i, j);
+    int s = 0, t = l;
+    do {
+        t = (t + 1) / 2;
+        if (delta(keys, n, i, i + (s + t) * d) > dnode) s += t;
+    } while (t > 1);
+    int gamma = i + s * d + min(d, 0);
+    int lo = min(i, j), hi = max(i, j);
+    int c0, c1;
+    if (lo == gamma) { c0 = ~gamma; leaf_parent[gamma] = i; } else { c0 = gamma; parent[gamma] = i; }
+    if (hi == gamma + 1) { c1 = ~(gamma + 1); leaf_parent[gamma + 1] = i; } else { c1 = gamma + 1; parent[gamma + 1] = i; }
+    child[i] = make_int2(c0, c1);
+    if (i == 0) parent[0] = -1;
+}
+
+// Bottom-up fit, one lane per leaf.  The first lane to reach a node parks its box and leaves;
+// the second reads it and carries the union upward.  The parked box crosses CUs/XCDs inside
+// one launch, so it is published with an agent-scope release before the arrival counter and
+// read after an agent-scope acquire.
+__global__ __launch_bounds__(256) void k_fit(int n, const unsigned* __restrict__ vals, const float4* __restrict__ pbox,
+                                             const int2* __restrict__ child, const int* __restrict__ parent,
+                                             const int* __restrict__ leaf_parent, unsigned* __restrict__ arrived,
+                                             float4* __restrict__ parked, float4* __restrict__ nodes)
+{
+    int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    int prim = (int)vals[p];
+    float4 lo = pbox[2 * (size_t)prim], hi = pbox[2 * (size_t)prim + 1];
+    int me = ~p;            // code under which the parent knows this subtree
+    int out_code = ~prim;   // code written to the final node (leaves refer to primitive ids)
+    int node = leaf_parent[p];
+    for (int guard = 0; node >= 0 && guard < 4096; ++guard) {
+        int2 ch = child[node];
+        int side = ch.x == me ? 0 : 1;
+        float4* slot = parked + 4 * (size_t)node + 2 * side;
+        lo.w = __int_as_float(out_code);
+        slot[0] = lo; slot[1] = hi;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned old = atomicAdd(&arrived[node], 1u);
+        if (old == 0u) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        const float4* other = parked + 4 * (size_t)node + 2 * (1 - side);
+        float4 olo = other[0], ohi = other[1];
+        float4 lo0 = side == 0 ? lo : olo, hi0 = side == 0 ? hi : ohi;
+        float4 lo1 = side == 0 ? olo : lo, hi1 = side == 0 ? ohi : hi;
+        float4* nd = nodes + 4 * (size_t)node;
+        nd[0] = make_float4(lo0.x, lo0.y, lo0.z, hi0.x);
+        nd[1] = make_float4(hi0.y, hi0.z, lo1.x, lo1.y);
+        nd[2] = make_float4(lo1.z, hi1.x, hi1.y, hi1.z);
+        nd[3] = make_float4(lo0.w, lo1.w, 0.f, 0.f);
+        lo = make_float4(fminf(lo.x, olo.x), fminf(lo.y, olo.y), fminf(lo.z, olo.z), 0.f);
+        hi = make_float4(fmaxf(hi.x, ohi.x), fmaxf(hi.y, ohi.y), fmaxf(hi.z, ohi.z), 0.f);
+        me = node; out_code = node;
+        node = parent[node];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_depth(int n, const int* __restrict__ parent, const int* __restrict__ leaf_parent,
+                                               int* __restrict__ depth)
+{
+    int p = blockIdx.x * 256 + threadIdx.x;
+    int d = 0;
+    if (p < n) {
+        int node = leaf_parent[p];
+        while (node >= 0 && d < 4096) { ++d; node = parent[node]; }
+    }
+    for (int o = 32; o > 0; o >>= 1) d = max(d, __shfl_xor(d, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(depth, d);
+}
+
+} // namespace
+
+#define BCHK(expr) do { e = (expr); if (e != hipSuccess) goto done; } while (0)
+
+hipError_t vrt_build_lbvh(const DevScene& S, float4* nodes, int* depth_out, float* ms_out, hipStream_t stream)
+{
+    const int n = S.n_prims;
+    hipError_t e = hipSuccess;
+    float4 *pbox = nullptr, *parked = nullptr;
+    unsigned *cb = nullptr, *vals = nullptr, *vals2 = nullptr, *arrived = nullptr;
+    unsigned long long *keys = nullptr, *keys2 = nullptr;
+    int2* child = nullptr;
+    int *parent = nullptr, *leaf_parent = nullptr, *depth = nullptr;
+    void* tmp = nullptr; size_t tmp_bytes = 0;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    const int blocks = (n + 255) / 256;
+    const unsigned cb_init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
+    if (n < 2) return hipErrorInvalidValue;
+
+    BCHK(hipEventCreate(&e0)); BCHK(hipEventCreate(&e1));
+    BCHK(hipMalloc(&pbox, 2 * (size_t)n * sizeof(float4)));
+    BCHK(hipMalloc(&parked, 4 * (size_t)(n - 1) * sizeof(float4)));
+    BCHK(hipMalloc(&cb, 6 * sizeof(unsigned)));
+    BCHK(hipMalloc(&keys, (size_t)n * 8)); BCHK(hipMalloc(&keys2, (size_t)n * 8));
+    BCHK(hipMalloc(&vals, (size_t)n * 4)); BCHK(hipMalloc(&vals2, (size_t)n * 4));
+    BCHK(hipMalloc(&arrived, (size_t)(n - 1) * 4));
+    BCHK(hipMalloc(&child, (size_t)(n - 1) * sizeof(int2)));
+    BCHK(hipMalloc(&parent, (size_t)(n - 1) * 4));
+    BCHK(hipMalloc(&leaf_parent, (size_t)n * 4));
+    BCHK(hipMalloc(&depth, 4));
+    BCHK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, keys2, vals, vals2, (size_t)n, 0, 63, stream));
+    BCHK(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
+
+    BCHK(hipMemcpyAsync(cb, cb_init, sizeof cb_init, hipMemcpyHostToDevice, stream));
+    BCHK(hipMemsetAsync(arrived, 0, (size_t)(n - 1) * 4, stream));
+    BCHK(hipMemsetAsync(depth, 0, 4, stream));
+    BCHK(hipEventRecord(e0, stream));
+    hipLaunchKernelGGL(k_prim_bounds, dim3(blocks), dim3(256), 0, stream, S, pbox, cb);
+    hipLaunchKernelGGL(k_morton, dim3(blocks), dim3(256), 0, stream, n, pbox, cb, keys, vals);
+    BCHK(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys2, vals, vals2, (size_t)n, 0, 63, stream));
+    hipLaunchKernelGGL(k_hierarchy, dim3(blocks), dim3(256), 0, stream, n, keys2, child, parent, leaf_parent);
+    hipLaunchKernelGGL(k_fit, dim3(blocks), dim3(256), 0, stream, n, vals2, pbox, child, parent, leaf_parent, arrived,
+                       parked, nodes);
+    hipLaunchKernelGGL(k_depth, dim3(blocks), dim3(256), 0, stream, n, parent, leaf_parent, depth);
+    BCHK(hipEventRecord(e1, stream));
+    BCHK(hipGetLastError());
+    BCHK(hipStreamSynchronize(stream));
+    BCHK(hipMemcpy(depth_out, depth, 4, hipMemcpyDeviceToHost));
+    BCHK(hipEventElapsedTime(ms_out, e0, e1));
+done:
+    hipFree(pbox); hipFree(parked); hipFree(cb); hipFree(keys); hipFree(keys2); hipFree(vals); hipFree(vals2);
+    hipFree(arrived); hipFree(child); hipFree(parent); hipFree(leaf_parent); hipFree(depth); hipFree(tmp);
+    if (e0) hipEventDestroy(e0);
+    if (e1) hipEventDestroy(e1);
+    return e;
+}

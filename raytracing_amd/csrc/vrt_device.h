@@ -55,6 +55,7 @@ struct DevParams {
     // strip sharding: local row r -> global row
     int tile_index, tile_count, tile_rows;
     int local_rows; // rows this call renders
+    int compact;    // outputs indexed by local row instead of global row
 };
 
 // Per-call ray counters: 256 slots x 8 words to spread atomic traffic, summed by the host.

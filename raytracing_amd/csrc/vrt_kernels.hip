@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void k_mega(DevScene S, DevCam cam, DevParams 
     if (v < cam.width && r < P.local_rows && h < cam.height) {
         int id;
         float4 c = trace_pixel_dev<BVH, false, TWOCHILD>(S, cam, P, h, v, -1, id, C, R);
-        size_t idx = (size_t)h * cam.width + v; // RayTracerUnity.cs:442
+        size_t idx = (size_t)(P.compact ? r : h) * cam.width + v; // RayTracerUnity.cs:442
         rgba[idx] = c;
         if (hit_id) hit_id[idx] = id;
     }

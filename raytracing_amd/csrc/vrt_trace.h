@@ -184,7 +184,8 @@ __device__ __forceinline__ Hit intersect_bvh(const DevScene& S, f3 o, f3 d, floa
     int stack[VRT_BVH_STACK];
     int sp = 0;
     int node = 0;
-    for (;;) {
+    // every internal node is entered at most once; the bound only guards against a corrupt tree
+    for (int guard = S.n_prims + 8; guard > 0; --guard) {
         const float4* n = S.bvh + 4 * (size_t)node;
         float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
         int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);

@@ -13,7 +13,8 @@ class Params:
     and Assets/Scripts/RayTracer/Util/RayTraceUtility.cs:81,461): range 30, MaxDepth 10."""
 
     def __init__(self, spp=1, offsets=None, seed=0, max_depth=10, rng=30.0, flags=0,
-                 mode=abi.VRT_MODE_AUTO, tile_index=0, tile_count=1, tile_rows=8):
+                 mode=abi.VRT_MODE_AUTO, tile_index=0, tile_count=1, tile_rows=8,
+                 compact_rows=False):
         self.c = abi.vrt_params()
         self.c.spp = spp
         self.offsets = None
@@ -31,6 +32,7 @@ class Params:
         self.c.flags = flags
         self.c.mode = mode
         self.c.tile_index, self.c.tile_count, self.c.tile_rows = tile_index, tile_count, tile_rows
+        self.c.compact_rows = int(compact_rows)
         self._rec = None
 
     def record(self, pixels, cap):
