@@ -1,0 +1,249 @@
+#!/usr/bin/env python3
+"""Benchmark of the per-pixel tracing loop on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--workload c2|c3|c4] [--mode auto|mega|wavefront]
+
+A step = one frame of the workload rendered by libvrt with camera/scene resident on the GPU
+and the framebuffer left in HBM.  At N = 1 the default workload is the teaching scene at
+1920x1080, 1 spp, reflection depth 5.  With N > 1 (one process per GPU under
+torch.distributed.run) the frame grows with N (same scene and camera, N times the pixels),
+is cut into 8-row strips dealt round-robin to the ranks, and the strips are gathered to rank 0
+with RCCL and de-interleaved there: per-GPU work is fixed, i.e. weak scaling.
+
+Rank 0 prints one JSON line.  `value` is Mrays/s over all GPUs, a ray being one intersection
+query (primary + reflection + transmission + shadow + ambient-occlusion; the reference's
+redundant primary pre-check is not counted).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import raytracing_amd as ra  # noqa: E402
+from raytracing_amd import abi, host  # noqa: E402
+
+# Frame per world size: ~N x the pixels of 1920x1080, 16:9, height a multiple of 8*N rows.
+FRAMES = {1: (1920, 1080), 2: (2720, 1520), 4: (3840, 2176), 8: (5440, 3072)}
+PEAK_FP32_TFLOPS = 157.3   # MI355X vector FP32 (MI355X_MICROARCH.md, chip-level parameters)
+PEAK_HBM_GBPS = 8000.0
+
+
+def build_workload(name, n_gpus):
+    if name == "c2":
+        w, h = FRAMES.get(n_gpus, (1920, 1080 * n_gpus))
+        scene = ra.teaching_scene()
+        # keep the field of view of the 16:9 frame whatever the pixel count
+        cam = ra.make_camera((1.45, 2.0, 2.5), (3.0, 1.55, 2.5 + (16 / 9) / 2), (0.0, 0.0, -16 / 9),
+                             (0.0, 1.0, 0.0), w, h)
+        kw = dict(spp=1, max_depth=5, rng=30.0)
+        label = f"teaching scene {w}x{h}, 1 spp, depth 5"
+        offsets = None
+    elif name == "c3":
+        w, h = (3840, 2160)
+        scene = ra.random_spheres_scene(10000)
+        cam = ra.random_spheres_camera(w, h)
+        offsets = host.sampler_table(abi.VRT_SAMPLER_JITTERED, 16, 83, 2.4 * (w / h) / w, 2.4 / h, seed=1)
+        kw = dict(spp=16, max_depth=8, rng=200.0, seed=1)
+        label = f"10k random spheres {w}x{h}, 16 spp jittered, depth 8"
+    elif name == "c4":
+        w, h = (1920, 1080)
+        scene = ra.tessellated_mesh_scene(708)
+        cam = ra.tessellated_mesh_camera(w, h)
+        offsets = host.sampler_table(abi.VRT_SAMPLER_JITTERED, 4, 83, 2.0 * (w / h) / w, 2.0 / h, seed=1)
+        kw = dict(spp=4, max_depth=5, rng=100.0, seed=1)
+        label = f"1M-triangle mesh {w}x{h}, 4 spp jittered, depth 5"
+    else:
+        raise SystemExit(f"unknown workload {name}")
+    return scene, cam, offsets, kw, label
+
+
+def algorithmic_flops(scene, rays, pixels):
+    """FP32 operations the brute-force path needs for these ray counts: every query walks all
+    primitives (17 per sphere, 30 per box, 40 per triangle), each shaded hit costs
+    25 + 30 per light, each primary ray 12 for ray generation and each secondary miss 8 for the
+    sky colour.  Shaded hits are bounded by primary + reflection + transmission rays."""
+    per_query = 17 * len(scene.spheres) + 30 * len(scene.boxes) + 40 * len(scene.indices)
+    queries = sum(int(r) for r in rays[1:])
+    shaded = int(rays[abi.VRT_RAY_PRIMARY] + rays[abi.VRT_RAY_REFLECT] + rays[abi.VRT_RAY_TRANSMIT])
+    return queries * per_query + shaded * (25 + 30 * len(scene.lights)) + pixels * 12 + shaded * 8
+
+
+def cpu_baseline(scene, cam, prm):
+    """Times the CPU oracle (a restatement of the reference algorithm, not the Unity player) on
+    this host: the whole frame once on one core, then once on all cores the box grants us."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle
+    oracle.build()
+    # bounded sample: the same camera and scene at a pixel count that keeps pixels x spp near
+    # the 1080p single-sample frame (the whole frame for the default workload)
+    scale = max(1.0, (cam.width * cam.height * prm.c.spp / 2.1e6) ** 0.5)
+    sw, sh = max(int(cam.width / scale), 1), max(int(cam.height / scale), 1)
+    scam = ra.make_camera(cam.origin[:], cam.p0[:], cam.x_axis[:], cam.y_axis[:], sw, sh)
+    t0 = time.perf_counter()
+    _, _, rays = oracle.render(scene, scam, prm.c, n_threads=1)
+    t1 = time.perf_counter()
+    nthr = min(16, os.cpu_count() or 1)
+    _, _, rays2 = oracle.render(scene, scam, prm.c, n_threads=nthr)
+    t2 = time.perf_counter()
+    q = float(sum(int(r) for r in rays[1:]))
+    return {"value": q / (t1 - t0) / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port",
+            "sample": f"{sw}x{sh} sub-frame of the same camera and scene ({q:.0f} rays), oracle/vrt_oracle.c serial",
+            "ms_per_sample_frame": (t1 - t0) * 1e3,
+            "omp_value": q / (t2 - t1) / 1e6, "omp_cores": nthr}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="c2")
+    ap.add_argument("--mode", default="auto", choices=["auto", "mega", "wavefront"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    scene, cam, offsets, kw, label = build_workload(args.workload, world)
+    mode = {"auto": abi.VRT_MODE_AUTO, "mega": abi.VRT_MODE_MEGAKERNEL, "wavefront": abi.VRT_MODE_WAVEFRONT}[args.mode]
+    prm = ra.Params(offsets=offsets, mode=mode, tile_index=rank, tile_count=world, tile_rows=8,
+                    compact_rows=world > 1, **kw)
+    ctx = host.Context(local_rank)
+    ctx.set_scene(scene)
+    ctx.set_camera(cam)
+
+    W, H = cam.width, cam.height
+    rows = H if world == 1 else H // world
+    if world > 1:
+        assert H % (8 * world) == 0
+    local = torch.empty((rows, W, 4), dtype=torch.float32, device=dev)
+    local_hit = torch.empty((rows, W), dtype=torch.int32, device=dev)
+    gathered = final = None
+    if world > 1 and rank == 0:
+        gathered = [torch.empty_like(local) for _ in range(world)]
+        final = torch.empty((H, W, 4), dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream()
+
+    def step():
+        ctx.render_device(prm, local.data_ptr(), local_hit.data_ptr(), stream.cuda_stream)
+        if world > 1:
+            dist.gather(local, gathered, dst=0)
+            if rank == 0:
+                # strips s = k*world + r of rank r, 8 rows each -> global row order
+                g = torch.stack(gathered, 0).view(world, H // (8 * world), 8, W, 4)
+                final.view(H // (8 * world), world, 8, W, 4).copy_(g.permute(1, 0, 2, 3, 4))
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    st = ctx.fetch_stats()
+    rays = np.array(st.rays[:], np.int64)
+    my_queries = int(rays[1:].sum())
+
+    # kernel-only time of the render launches (events on the launch stream, no gather)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record(stream)
+    for _ in range(args.steps):
+        ctx.render_device(prm, local.data_ptr(), local_hit.data_ptr(), stream.cuda_stream)
+    ev1.record(stream)
+    torch.cuda.synchronize()
+    kernel_ms = ev0.elapsed_time(ev1) / max(args.steps, 1)
+
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+
+    tot = torch.tensor([elapsed, float(my_queries)], dtype=torch.float64, device=dev)
+    if world > 1:
+        mx = tot.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = tot.clone()
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        elapsed, queries = float(mx[0]), float(sm[1])
+    else:
+        queries = float(my_queries)
+
+    if rank == 0:
+        ms_per_step = elapsed * 1e3 / args.steps
+        flops = algorithmic_flops(scene, rays, st.pixels)
+        fb_bytes = st.pixels * 20
+        if ctx.fetch_stats().bvh_nodes == 0:
+            ach = flops / (kernel_ms * 1e-3) / 1e12
+            roof = {"bound": "valu", "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                    "frac": ach / PEAK_FP32_TFLOPS, "traffic": None,
+                    "kernel": "k_mega<brute>" if st.mode_used == abi.VRT_MODE_MEGAKERNEL else "k_wf_*",
+                    "kernel_ms": kernel_ms, "algorithmic_flops_per_launch": flops,
+                    "framebuffer_bytes_per_launch": fb_bytes,
+                    "hbm_achieved_GBps": fb_bytes / (kernel_ms * 1e-3) / 1e9,
+                    "note": "FP32 vector-ALU bound (no dense contraction, primitives in scalar registers); "
+                            "peak is the MI355X FP32 vector rate"}
+        else:
+            by = my_queries * 120 + fb_bytes
+            ach = by / (kernel_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                    "frac": ach / PEAK_HBM_GBPS, "traffic": None, "kernel_ms": kernel_ms,
+                    "algorithmic_bytes_per_launch": by,
+                    "note": "120 B per ray (ray + hit records) + 20 B per pixel; BVH node traffic not included"}
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                roof["traffic"] = json.load(open(tpath)).get(args.workload)
+            except Exception:
+                pass
+        out = {
+            "metric": "Mrays/s (primary+secondary) at 1080p depth 5",
+            "value": queries * args.steps / elapsed / 1e6,
+            "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": label, "frame": [W, H], "rays_per_frame": queries,
+                       "mode": "wavefront" if st.mode_used == abi.VRT_MODE_WAVEFRONT else "megakernel",
+                       "gather": "rccl gather to rank 0" if world > 1 else "none",
+                       "rays_by_class": {n: int(r) for n, r in zip(abi.RAY_CLASS_NAMES, rays)}},
+            "ms_per_frame_kernel": kernel_ms,
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(scene, cam, prm)
+            out["gpu_over_cpu_serial"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -242,10 +242,10 @@ def random_spheres_scene(n=10000, seed=0xC0FFEE):
 
 def random_spheres_camera(width=3840, height=2160):
     """Looks along +z and slightly down over the sphere field; range must cover the scene."""
-    o = np.array([0.0, 12.0, -48.0])
-    centre = np.array([0.0, 8.5, -44.0])
-    fwd = centre - o
+    o = np.array([0.0, 14.0, -42.0])
+    fwd = np.array([0.0, 3.0, -5.0]) - o
     fwd /= np.linalg.norm(fwd)
+    centre = o + 4.0 * fwd
     right = np.cross([0.0, 1.0, 0.0], fwd)
     right /= np.linalg.norm(right)
     up = np.cross(fwd, right)
