@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -20,6 +21,7 @@ struct vrt_ctx {
     // scene
     float4 *d_sph = nullptr, *d_box = nullptr, *d_tri = nullptr, *d_mat = nullptr, *d_bvh = nullptr;
     int* d_prim_mat = nullptr;
+    DevLight* d_lights = nullptr;
     DevScene scene;
     bool have_scene = false, use_bvh = false;
     float bvh_ms = 0.f;
@@ -106,7 +108,8 @@ extern "C" int vrt_create(int device, vrt_ctx** out)
 static void free_scene(vrt_ctx* c)
 {
     hipFree(c->d_sph); hipFree(c->d_box); hipFree(c->d_tri); hipFree(c->d_mat); hipFree(c->d_bvh);
-    hipFree(c->d_prim_mat);
+    hipFree(c->d_prim_mat); hipFree(c->d_lights);
+    c->d_lights = nullptr;
     c->d_sph = c->d_box = c->d_tri = c->d_mat = c->d_bvh = nullptr;
     c->d_prim_mat = nullptr;
     c->have_scene = false;
@@ -214,14 +217,18 @@ extern "C" int vrt_set_scene(vrt_ctx* c, const vrt_scene_desc* d)
     S.n_prims = (int)n_prims;
     S.sph = c->d_sph; S.box = c->d_box; S.tri = c->d_tri; S.prim_mat = c->d_prim_mat; S.mat = c->d_mat;
     S.n_lights = (int)d->n_lights;
+    std::vector<DevLight> lights(d->n_lights ? d->n_lights : 1);
+    memset(lights.data(), 0, lights.size() * sizeof(DevLight));
     for (uint32_t i = 0; i < d->n_lights; ++i) {
         const vrt_light& l = d->lights[i];
         if (l.type != VRT_LIGHT_DIRECTIONAL && l.type != VRT_LIGHT_POINT) return fail(c, VRT_ERR_INVALID, "bad light type");
-        DevLight& o = S.lights[i];
+        DevLight& o = lights[i];
         o.type = l.type; o.vx = l.vec[0]; o.vy = l.vec[1]; o.vz = l.vec[2]; o.ls = l.ls;
         o.cr = l.color[0]; o.cg = l.color[1]; o.cb = l.color[2]; o.cast = l.cast_shadows;
         o.lx = l.location[0]; o.ly = l.location[1]; o.lz = l.location[2];
     }
+    HIPCHK(c, upload(&c->d_lights, lights));
+    S.lights = c->d_lights;
     S.sh = d->shading;
 
     c->use_bvh = n_prims > kBruteMaxPrims;
@@ -284,6 +291,11 @@ static int prepare(vrt_ctx* c, const vrt_params* p, DevParams* out)
     P.tile_rows = p->tile_rows > 0 ? p->tile_rows : 8;
     P.local_rows = owned_rows(c->cam.height, P.tile_index, tcount, P.tile_rows);
     P.compact = p->compact_rows != 0;
+    // Measured on MI355X: giving each XCD one contiguous band of the image costs 1.4-1.7x on
+    // every workload (bands differ in work, the slowest XCD sets the frame time), so blocks
+    // keep the hardware's round-robin deal; VRT_XCD_REMAP=1 re-enables the banding for study.
+    P.xcd_remap = 0;
+    if (const char* e = getenv("VRT_XCD_REMAP")) P.xcd_remap = atoi(e);
     P.offsets = nullptr;
     if (p->offsets) {
         size_t n = (size_t)p->n_sets * p->spp;

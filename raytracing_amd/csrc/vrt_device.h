@@ -33,7 +33,7 @@ struct DevScene {
     const float4* mat;
     const float4* bvh;
     int n_lights;
-    DevLight lights[VRT_MAX_LIGHTS];
+    const DevLight* lights; // n_lights entries in device memory
     vrt_shading sh;
 };
 
@@ -56,6 +56,7 @@ struct DevParams {
     int tile_index, tile_count, tile_rows;
     int local_rows; // rows this call renders
     int compact;    // outputs indexed by local row instead of global row
+    int xcd_remap;  // renumber blocks so that each XCD works on one contiguous band of tiles
 };
 
 // Per-call ray counters: 256 slots x 8 words to spread atomic traffic, summed by the host.

@@ -45,26 +45,35 @@ __device__ __forceinline__ void flush_counters(const Counters& C, unsigned long 
 // full 128-byte framebuffer lines per wave store); a block covers 32x8 pixels.
 // Blocks are renumbered so that the 8 blocks dealt round-robin to the 8 XCDs come from 8
 // separate bands of the image and each XCD's L2 keeps seeing neighbouring tiles.
+#ifndef VRT_MEGA_THREADS
+#define VRT_MEGA_THREADS 64
+#endif
 template <bool BVH, bool TWOCHILD>
-__global__ __launch_bounds__(256) void k_mega(DevScene S, DevCam cam, DevParams P, float4* __restrict__ rgba,
+__global__ __launch_bounds__(VRT_MEGA_THREADS) void k_mega(DevScene S, DevCam cam, DevParams P, float4* __restrict__ rgba,
                                               int* __restrict__ hit_id, unsigned long long* ctr,
                                               int blocks_x, int n_blocks)
 {
     unsigned bid = blockIdx.x;
     {   // bijective XCD remap: label = bid % 8 selects a contiguous band of block ids
         unsigned q = n_blocks / 8, r = n_blocks % 8, xcd = bid % 8, k = bid / 8;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+        if (P.xcd_remap) bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
     }
     int bx = bid % blocks_x, by = bid / blocks_x;
     int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    int v = bx * 32 + wave * 8 + (lane & 7);
+    int v = bx * (VRT_MEGA_THREADS / 8) + wave * 8 + (lane & 7);
     int r = by * 8 + (lane >> 3);
     int h = local_to_global_row(P, r);
     Counters C = {0, 0, 0, 0, 0, 0};
     Recorder R; R.segs = nullptr; R.cap = 0; R.n = 0; R.sample = 0;
+    __shared__ LdsScene s_scene;
+    stage_scene(S, &s_scene);
     if (v < cam.width && r < P.local_rows && h < cam.height) {
         int id;
+#if VRT_USE_SM
+        float4 c = trace_pixel_sm<BVH, false, TWOCHILD>(S, cam, P, &s_scene, h, v, -1, id, C, R);
+#else
         float4 c = trace_pixel_dev<BVH, false, TWOCHILD>(S, cam, P, h, v, -1, id, C, R);
+#endif
         size_t idx = (size_t)(P.compact ? r : h) * cam.width + v; // RayTracerUnity.cs:442
         rgba[idx] = c;
         if (hit_id) hit_id[idx] = id;
@@ -82,12 +91,14 @@ __global__ __launch_bounds__(64) void k_pixels(DevScene S, DevCam cam, DevParams
 {
     int i = blockIdx.x * 64 + threadIdx.x;
     Counters C = {0, 0, 0, 0, 0, 0};
+    __shared__ LdsScene s_scene;
+    stage_scene(S, &s_scene);
     if (i < n_pixels) {
         int pix = pixels[i];
         int h = pix / cam.width, v = pix % cam.width;
         Recorder R; R.segs = segs + (size_t)i * cap; R.cap = cap; R.n = 0; R.sample = 0;
         int id;
-        float4 c = trace_pixel_dev<BVH, true, TWOCHILD>(S, cam, P, h, v, sample_sel, id, C, R);
+        float4 c = trace_pixel_sm<BVH, true, TWOCHILD>(S, cam, P, &s_scene, h, v, sample_sel, id, C, R);
         seg_counts[i] = R.n;
         if (rgba_out) rgba_out[i] = c;
         if (hit_out) hit_out[i] = id;
@@ -102,10 +113,10 @@ static inline int div_up(int a, int b) { return (a + b - 1) / b; }
 hipError_t vrt_launch_mega(const DevScene& S, const DevCam& cam, const DevParams& P, bool bvh, bool twochild,
                            float4* rgba, int* hit_id, unsigned long long* ctr, hipStream_t stream)
 {
-    int blocks_x = div_up(cam.width, 32), blocks_y = div_up(P.local_rows, 8);
+    int blocks_x = div_up(cam.width, VRT_MEGA_THREADS / 8), blocks_y = div_up(P.local_rows, 8);
     int n_blocks = blocks_x * blocks_y;
     if (n_blocks <= 0) return hipSuccess;
-    dim3 grid(n_blocks), block(256);
+    dim3 grid(n_blocks), block(VRT_MEGA_THREADS);
 #define VRT_GO(B, T) hipLaunchKernelGGL((k_mega<B, T>), grid, block, 0, stream, S, cam, P, rgba, hit_id, ctr, blocks_x, n_blocks)
     if (bvh) { if (twochild) VRT_GO(true, true); else VRT_GO(true, false); }
     else     { if (twochild) VRT_GO(false, true); else VRT_GO(false, false); }

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void k_wf_primary(DevScene S, DevCam cam, DevP
     unsigned bid = blockIdx.x;
     {
         unsigned q = n_blocks / 8, r = n_blocks % 8, xcd = bid % 8, k = bid / 8;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+        if (P.xcd_remap) bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
     }
     int bx = bid % blocks_x, by = bid / blocks_x;
     int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;

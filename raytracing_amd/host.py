@@ -9,7 +9,8 @@ import numpy as np
 
 from . import abi
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libvrt.so")
+# VRT_LIB points at an alternative build of the same library (kernel A/B experiments).
+_LIB_PATH = os.environ.get("VRT_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libvrt.so")
 _lib = None
 
 
