@@ -28,7 +28,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 import raytracing_amd as ra  # noqa: E402
-from raytracing_amd import abi, host  # noqa: E402
+from raytracing_amd import abi, host, tiles  # noqa: E402
 
 # Frame per world size: ~N x the pixels of 1920x1080, 16:9, height a multiple of 8*N rows.
 FRAMES = {1: (1920, 1080), 2: (2720, 1520), 4: (3840, 2176), 8: (5440, 3072)}
@@ -127,31 +127,21 @@ def main():
     scene, cam, offsets, kw, label = build_workload(args.workload, world)
     mode = {"auto": abi.VRT_MODE_AUTO, "mega": abi.VRT_MODE_MEGAKERNEL, "wavefront": abi.VRT_MODE_WAVEFRONT}[args.mode]
     prm = ra.Params(offsets=offsets, mode=mode, tile_index=rank, tile_count=world, tile_rows=8,
-                    compact_rows=world > 1, **kw)
+                    compact_rows=True, **kw)
     ctx = host.Context(local_rank)
     ctx.set_scene(scene)
     ctx.set_camera(cam)
 
     W, H = cam.width, cam.height
-    rows = H if world == 1 else H // world
-    if world > 1:
-        assert H % (8 * world) == 0
-    local = torch.empty((rows, W, 4), dtype=torch.float32, device=dev)
-    local_hit = torch.empty((rows, W), dtype=torch.int32, device=dev)
-    gathered = final = None
-    if world > 1 and rank == 0:
-        gathered = [torch.empty_like(local) for _ in range(world)]
-        final = torch.empty((H, W, 4), dtype=torch.float32, device=dev)
+    fg = tiles.FrameGather(H, W, 4, world, rank, 8, dev)
+    local = fg.local
+    local_hit = torch.empty((fg.rows_max, W), dtype=torch.int32, device=dev)
     stream = torch.cuda.current_stream()
 
     def step():
         ctx.render_device(prm, local.data_ptr(), local_hit.data_ptr(), stream.cuda_stream)
         if world > 1:
-            dist.gather(local, gathered, dst=0)
-            if rank == 0:
-                # strips s = k*world + r of rank r, 8 rows each -> global row order
-                g = torch.stack(gathered, 0).view(world, H // (8 * world), 8, W, 4)
-                final.view(H // (8 * world), world, 8, W, 4).copy_(g.permute(1, 0, 2, 3, 4))
+            fg.gather()  # RCCL gather of the packed strips to rank 0 + de-interleave there
 
     for _ in range(args.warmup):
         step()

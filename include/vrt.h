@@ -251,6 +251,14 @@ int vrt_trace_pixel(vrt_ctx* ctx, const vrt_params* params, int h, int v, int sa
                     vrt_path_seg* segs, int cap, int* n_out, float rgba[4],
                     int32_t* hit_id_out);
 
+/* One ray through the tracer: AbstractTracer.TraceRay(Ray ray, int depth)
+ * (Tracer/AbstractTracer.cs:9, Tracer/WhittedTracer.cs:33-104), for legacy per-ray callers and
+ * material code that recurses by hand.  `direction` is normalised like the Ray constructor does;
+ * the result is the raw radiance (no averaging, no tone mapping), alpha = 1.  depth >
+ * max_depth returns black without casting anything. */
+int vrt_trace_ray(vrt_ctx* ctx, const vrt_params* params, const float origin[3], const float direction[3],
+                  int depth, float rgba[4], int32_t* hit_id_out);
+
 /* Host-side sampler tables (Sampler/{Regular,Random,Jittered,NRooks,MultiJittered,Hammersley}Sampler.cs, Sampler/AbstractSampler.cs:37-52,143-182):
  * writes n_sets * n_samples (x,y) pairs in access order.  UnityEngine.Random is replaced
  * by PCG32 seeded with `seed`.  Needs no GPU. */

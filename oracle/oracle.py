@@ -84,6 +84,16 @@ def trace_pixel(scene, cam, params, h, v, sample=-1, cap=256):
     return np.array(rgba[:], np.float32), hit.value, segs, n.value, rays
 
 
+def trace_ray(scene, params, o, dirv, depth=0):
+    d = scene.desc()
+    rgba = (C.c_float * 4)()
+    hit = C.c_int32(-1)
+    rays = np.zeros(abi.VRT_RAY_CLASSES, np.uint64)
+    lib().vrto_trace_ray(C.byref(d), C.byref(params), _f3(o), _f3(dirv), depth, rgba, C.byref(hit),
+                         C.c_void_p(rays.ctypes.data))
+    return np.array(rgba[:], np.float32), hit.value, rays
+
+
 def intersect(scene, o, dirv, maxd=30.0, skip=-1, any_hit=False, force_brute=False):
     d = scene.desc()
     t = C.c_float(0)

@@ -700,6 +700,24 @@ int vrto_trace_pixel(const vrt_scene_desc* scene, const vrt_camera* cam, const v
     return 0;
 }
 
+/* AbstractTracer.TraceRay(ray, depth) for one ray (Tracer/WhittedTracer.cs:33-104). */
+int vrto_trace_ray(const vrt_scene_desc* scene, const vrt_params* prm, const float o[3], const float d[3],
+                   int depth, float rgba[4], int32_t* hit_id, uint64_t* rays_out)
+{
+    oscene s; scene_init(&s, scene);
+    octx c; memset(&c, 0, sizeof c); c.scene = &s; c.prm = prm;
+    oray r = make_ray(V(o[0], o[1], o[2]), V(d[0], d[1], d[2]));
+    if (hit_id) {
+        *hit_id = -1;
+        if (depth <= prm->max_depth) *hit_id = intersect(&s, r, prm->range, -1, 0).prim;
+    }
+    col px = trace_ray(&c, r, depth, -1, depth == 0 ? VRT_RAY_PRIMARY : VRT_RAY_REFLECT);
+    rgba[0] = px.r; rgba[1] = px.g; rgba[2] = px.b; rgba[3] = px.a;
+    if (rays_out) memcpy(rays_out, c.rays, sizeof c.rays);
+    scene_free(&s);
+    return 0;
+}
+
 /* Single queries, for unit tests of the pieces. */
 int vrto_intersect(const vrt_scene_desc* scene, const float o[3], const float d[3], float maxd,
                    int skip, int any, int force_brute, float* t, int32_t* prim, float point[3], float normal[3])

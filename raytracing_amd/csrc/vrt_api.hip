@@ -497,6 +497,29 @@ extern "C" int vrt_trace_pixel(vrt_ctx* c, const vrt_params* p, int h, int v, in
     return VRT_OK;
 }
 
+extern "C" int vrt_trace_ray(vrt_ctx* c, const vrt_params* p, const float origin[3], const float direction[3],
+                             int depth, float rgba[4], int32_t* hit_id_out)
+{
+    if (!c || !p || !origin || !direction || !rgba) return fail(c, VRT_ERR_INVALID, "null argument");
+    if (depth < 0) return fail(c, VRT_ERR_INVALID, "negative depth");
+    HIPCHK(c, hipSetDevice(c->device));
+    DevParams P;
+    int rc = prepare(c, p, &P);
+    if (rc) return rc;
+    HIPCHK(c, hipMemsetAsync(c->d_ctr, 0, VRT_CTR_SLOTS * VRT_CTR_STRIDE * sizeof(unsigned long long), c->stream));
+    bool two = (p->flags & VRT_FIX_DIELECTRIC) != 0;
+    HIPCHK(c, vrt_launch_ray(c->scene, P, c->use_bvh, two, origin, direction, depth, c->d_px_rgba, c->d_px_hit,
+                             c->d_ctr, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    float4 col; int id;
+    HIPCHK(c, hipMemcpy(&col, c->d_px_rgba, sizeof col, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(&id, c->d_px_hit, sizeof id, hipMemcpyDeviceToHost));
+    rgba[0] = col.x; rgba[1] = col.y; rgba[2] = col.z; rgba[3] = col.w;
+    if (hit_id_out) *hit_id_out = id;
+    c->last_pixels = 0; c->last_mode = VRT_MODE_MEGAKERNEL; c->timed = false;
+    return VRT_OK;
+}
+
 extern "C" uint32_t vrt_pixel_set(uint32_t seed, uint32_t pixel, uint32_t n_sets)
 {
     if (n_sets <= 1u) return 0u;

@@ -106,6 +106,35 @@ __global__ __launch_bounds__(64) void k_pixels(DevScene S, DevCam cam, DevParams
     if (ctr) flush_counters(C, ctr, blockIdx.x);
 }
 
+// ------------------------------------------------------------------ single ray
+
+// AbstractTracer.TraceRay(ray, depth) for one caller-supplied ray (Tracer/WhittedTracer.cs:33-104).
+template <bool BVH, bool TWOCHILD>
+__global__ __launch_bounds__(64) void k_ray(DevScene S, DevParams P, float ox, float oy, float oz, float dx, float dy,
+                                            float dz, int depth, float4* __restrict__ rgba_out,
+                                            int* __restrict__ hit_out, unsigned long long* ctr)
+{
+    Counters C = {0, 0, 0, 0, 0, 0};
+    if (threadIdx.x == 0) {
+        Recorder R; R.segs = nullptr; R.cap = 0; R.n = 0; R.sample = 0;
+        f3 o = mk3(ox, oy, oz), d = normalize3(mk3(dx, dy, dz));
+        f3 L = mk3(0.f, 0.f, 0.f);
+        int id = -1;
+        if (depth <= P.max_depth) {
+            Hit first; first.prim = -1; first.t = INFINITY; first.aux = 0;
+            if (!is_zero3(d)) {
+                if (depth == 0) C.primary++; else C.reflect++;
+                first = intersect<BVH, false>(S, o, d, P.range, -1);
+            }
+            id = first.prim;
+            L = first.prim >= 0 ? trace_path<BVH, false, TWOCHILD>(S, P, o, d, first, C, R, depth) : sky_color(d);
+        }
+        rgba_out[0] = make_float4(L.x, L.y, L.z, 1.f);
+        hit_out[0] = id;
+    }
+    flush_counters(C, ctr, 0);
+}
+
 // ------------------------------------------------------------------ launchers
 
 static inline int div_up(int a, int b) { return (a + b - 1) / b; }
@@ -132,6 +161,18 @@ hipError_t vrt_launch_pixels(const DevScene& S, const DevCam& cam, const DevPara
     if (n_pixels <= 0) return hipSuccess;
     dim3 grid(div_up(n_pixels, 64)), block(64);
 #define VRT_GO(B, T) hipLaunchKernelGGL((k_pixels<B, T>), grid, block, 0, stream, S, cam, P, pixels, n_pixels, sample_sel, segs, cap, seg_counts, rgba_out, hit_out, ctr)
+    if (bvh) { if (twochild) VRT_GO(true, true); else VRT_GO(true, false); }
+    else     { if (twochild) VRT_GO(false, true); else VRT_GO(false, false); }
+#undef VRT_GO
+    return hipGetLastError();
+}
+
+hipError_t vrt_launch_ray(const DevScene& S, const DevParams& P, bool bvh, bool twochild, const float o[3],
+                          const float d[3], int depth, float4* rgba_out, int* hit_out, unsigned long long* ctr,
+                          hipStream_t stream)
+{
+    dim3 grid(1), block(64);
+#define VRT_GO(B, T) hipLaunchKernelGGL((k_ray<B, T>), grid, block, 0, stream, S, P, o[0], o[1], o[2], d[0], d[1], d[2], depth, rgba_out, hit_out, ctr)
     if (bvh) { if (twochild) VRT_GO(true, true); else VRT_GO(true, false); }
     else     { if (twochild) VRT_GO(false, true); else VRT_GO(false, false); }
 #undef VRT_GO

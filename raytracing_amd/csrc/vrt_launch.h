@@ -10,6 +10,10 @@ hipError_t vrt_launch_pixels(const DevScene& S, const DevCam& cam, const DevPara
                              int* seg_counts, float4* rgba_out, int* hit_out, unsigned long long* ctr,
                              hipStream_t stream);
 
+hipError_t vrt_launch_ray(const DevScene& S, const DevParams& P, bool bvh, bool twochild, const float o[3],
+                          const float d[3], int depth, float4* rgba_out, int* hit_out, unsigned long long* ctr,
+                          hipStream_t stream);
+
 // Wavefront pipeline workspace: ray queues (two, ping-pong), per-pixel accumulators, counters.
 struct WfWorkspace {
     RayQueue q[2];

@@ -486,11 +486,11 @@ struct PendingRay { f3 o, d, T; int depth, skip, kind; };
 // refracting hit waits on a bounded per-lane stack.
 template <bool BVH, bool RECORD, bool TWOCHILD>
 __device__ __forceinline__ f3 trace_path(const DevScene& S, const DevParams& P, f3 o, f3 d, Hit first,
-                                         Counters& C, Recorder& R)
+                                         Counters& C, Recorder& R, int depth0 = 0)
 {
     f3 L = mk3(0.f, 0.f, 0.f);
     f3 T = mk3(1.f, 1.f, 1.f);
-    int depth = 0, skip = -1, kind = VRT_RAY_PRIMARY;
+    int depth = depth0, skip = -1, kind = VRT_RAY_PRIMARY;
     Hit h = first;
     bool have_first = true;
     PendingRay stack[TWOCHILD ? VRT_MAX_DEPTH + 2 : 1];

@@ -60,6 +60,9 @@ def load_library():
     L.vrt_trace_pixel.argtypes = [vp, C.POINTER(abi.vrt_params), C.c_int, C.c_int, C.c_int,
                                   C.POINTER(abi.vrt_path_seg), C.c_int, C.POINTER(C.c_int),
                                   C.POINTER(C.c_float), C.POINTER(C.c_int32)]
+    L.vrt_trace_ray.restype = C.c_int
+    L.vrt_trace_ray.argtypes = [vp, C.POINTER(abi.vrt_params), C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int32)]
     L.vrt_sampler_table.restype = C.c_int
     L.vrt_sampler_table.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_uint64, vp]
     L.vrt_pixel_set.restype = C.c_uint32
@@ -153,3 +156,12 @@ class Context:
                                             segs if cap > 0 else None, cap, C.byref(n), rgba,
                                             C.byref(hit)))
         return np.array(rgba[:], np.float32), hit.value, segs, n.value
+
+    def trace_ray(self, params, origin, direction, depth=0):
+        """AbstractTracer.TraceRay(ray, depth): raw radiance of one ray and its first hit id."""
+        o = (C.c_float * 3)(*[float(x) for x in origin])
+        d = (C.c_float * 3)(*[float(x) for x in direction])
+        rgba = (C.c_float * 4)()
+        hit = C.c_int32(-1)
+        self._chk(self._lib.vrt_trace_ray(self._h, C.byref(params.c), o, d, depth, rgba, C.byref(hit)))
+        return np.array(rgba[:], np.float32), hit.value

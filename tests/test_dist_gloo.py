@@ -1,0 +1,66 @@
+"""The N > 1 path on CPU: two gloo ranks shard the frame by strips, each renders its strips
+(with the CPU oracle standing in for the GPU), and the gathered frame must equal the
+single-process frame bit for bit."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import raytracing_amd as ra
+from raytracing_amd import tiles
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, height, width, tile_rows, out_path):
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    scene, cam = ra.teaching_scene(), ra.teaching_camera(width, height)
+    prm = ra.Params(spp=1, max_depth=3, tile_index=rank, tile_count=world, tile_rows=tile_rows)
+    rgba, hit, rays = oracle.render(scene, cam, prm.c)
+    rows = tiles.owned_rows(height, rank, world, tile_rows)
+    fg = tiles.FrameGather(height, width, 4, world, rank, tile_rows, torch.device("cpu"))
+    assert fg.n_local == len(rows)
+    fg.local[: len(rows)].copy_(torch.from_numpy(rgba[rows]))
+    total = torch.tensor([float(rays[1:].sum())], dtype=torch.float64)
+    dist.all_reduce(total)
+    final = fg.gather()
+    if rank == 0:
+        np.save(out_path, final.numpy())
+        np.save(out_path + ".rays.npy", total.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("height,width,tile_rows,world", [(48, 40, 8, 2), (50, 33, 8, 2), (20, 16, 4, 3)])
+def test_strip_sharding_and_gather(tmp_path, oracle_mod, height, width, tile_rows, world):
+    out = str(tmp_path / "frame.npy")
+    mp.spawn(_worker, args=(world, _free_port(), height, width, tile_rows, out), nprocs=world, join=True)
+    got = np.load(out)
+    scene, cam = ra.teaching_scene(), ra.teaching_camera(width, height)
+    ref, _, rays = oracle_mod.render(scene, cam, ra.Params(spp=1, max_depth=3).c)
+    assert np.array_equal(got, ref, equal_nan=True)
+    assert float(np.load(out + ".rays.npy")[0]) == float(rays[1:].sum())
+
+
+def test_owned_rows_partition():
+    for h, n, tr in [(1080, 1, 8), (1520, 2, 8), (2176, 4, 8), (3072, 8, 8), (50, 3, 8), (7, 4, 2)]:
+        seen = sorted(r for k in range(n) for r in tiles.owned_rows(h, k, n, tr))
+        assert seen == list(range(h))
+        assert tiles.max_owned_rows(h, n, tr) >= (h + n - 1) // n

@@ -112,3 +112,23 @@ def test_error_paths(vrt_ctx):
     with pytest.raises(host.VrtError):
         vrt_ctx.set_scene(bad)
     vrt_ctx.set_scene(scene)
+
+
+def test_trace_ray_matches_oracle(vrt_ctx, oracle_mod):
+    """vrt_trace_ray = AbstractTracer.TraceRay(ray, depth) for caller-supplied rays."""
+    scene = ra.teaching_scene()
+    vrt_ctx.set_scene(scene)
+    vrt_ctx.set_camera(ra.teaching_camera(8, 8))
+    prm = ra.Params(spp=1, max_depth=5)
+    rng = np.random.default_rng(3)
+    rays = [((1.45, 2, 2.5), (1, -0.1, 0.2), 0), ((1.45, 2, 2.5), (1, 0.5, 0), 0), ((1.45, 2, 2.5), (0, 0, 0), 0),
+            ((5.5, 3.0, 2.5), (0, -1, 0), 2), ((1.45, 2, 2.5), (1, -0.2, 0.0), 6), ((1.45, 2, 2.5), (1, -0.2, 0.0), 5)]
+    for _ in range(40):
+        rays.append(((1.45, 2, 2.5), (1.0, rng.uniform(-0.4, 0.4), rng.uniform(-0.6, 0.6)), int(rng.integers(0, 4))))
+    for o, d, depth in rays:
+        rgba, hit = vrt_ctx.trace_ray(prm, o, d, depth)
+        o_rgba, o_hit, o_rays = oracle_mod.trace_ray(scene, prm.c, o, d, depth)
+        assert hit == o_hit, (o, d, depth)
+        assert np.allclose(rgba[:3], o_rgba[:3], atol=1.0 / 255.0, equal_nan=True)  # callers read r,g,b only (RayTracerUnity.cs:585)
+        st = vrt_ctx.fetch_stats()
+        assert list(st.rays)[1:] == list(o_rays)[1:]
