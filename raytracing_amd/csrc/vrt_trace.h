@@ -190,39 +190,60 @@ __device__ __forceinline__ bool slab_test(f3 lo, f3 hi, f3 o, f3 inv, float tmax
     return t0 <= t1 * 1.0000004f;
 }
 
+// Lanes per block of the translation unit that includes this header; sizes the LDS stack.
+#ifndef VRT_STACK_LANES
+#define VRT_STACK_LANES 64
+#endif
+#define VRT_LDS_STACK 16
+
 // Stack-based traversal of the 2-wide LBVH, nearer child first.  The result does not depend
 // on the traversal order because candidates are ranked by (t, id).
+// Leaves go through the same loop head as inner nodes, so there is one primitive-test site and
+// lanes that sit on leaves run it together.  The first VRT_LDS_STACK stack entries of a lane
+// live in LDS ([entry][lane], conflict-free); deeper entries spill to private memory, which
+// real scenes rarely reach because only the far child of a two-hit node is ever pushed.
 __device__ __forceinline__ Hit intersect_bvh(const DevScene& S, f3 o, f3 d, float maxd, float tlim, int skip, bool ANY)
 {
+    __shared__ int lds_stack[VRT_LDS_STACK * VRT_STACK_LANES];
+    int* my_lds = lds_stack + threadIdx.x;
     Hit best; best.t = INFINITY; best.prim = -1; best.aux = 0;
     if (is_zero3(d)) return best;
     f3 inv = mk3(1.f / d.x, 1.f / d.y, 1.f / d.z);
-    int stack[VRT_BVH_STACK];
+    int deep[VRT_BVH_STACK - VRT_LDS_STACK];
     int sp = 0;
     int node = 0;
-    // every internal node is entered at most once; the bound only guards against a corrupt tree
-    for (int guard = S.n_prims + 8; guard > 0; --guard) {
-        const float4* n = S.bvh + 4 * (size_t)node;
-        float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
-        int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
-        float lim = best.prim >= 0 ? best.t : fminf(maxd, tlim);
-        float tn0, tn1;
-        bool h0 = slab_test(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), o, inv, lim, tn0);
-        bool h1 = slab_test(mk3(n1.z, n1.w, n2.x), mk3(n2.y, n2.z, n2.w), o, inv, lim, tn1);
-        if (h0 && c0 < 0) { if (~c0 != skip) test_prim(S, ~c0, o, d, maxd, best); h0 = false; }
-        if (h1 && c1 < 0) { if (~c1 != skip) test_prim(S, ~c1, o, d, maxd, best); h1 = false; }
-        if (ANY && best.prim >= 0) { if (best.t < tlim) return best; best.prim = -1; best.t = INFINITY; }
-        if (h0 && h1) {
-            int nearc = tn1 < tn0 ? c1 : c0, farc = tn1 < tn0 ? c0 : c1;
-            if (sp < VRT_BVH_STACK) stack[sp++] = farc;
-            node = nearc;
-        } else if (h0) {
-            node = c0;
-        } else if (h1) {
-            node = c1;
+    // every node is entered at most once; the bound only guards against a corrupt tree
+    for (int guard = 2 * S.n_prims + 8; guard > 0; --guard) {
+        bool pop = true;
+        if (node >= 0) {
+            const float4* n = S.bvh + 4 * (size_t)node;
+            float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
+            int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
+            float lim = best.prim >= 0 ? best.t : fminf(maxd, tlim);
+            float tn0, tn1;
+            bool h0 = slab_test(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), o, inv, lim, tn0);
+            bool h1 = slab_test(mk3(n1.z, n1.w, n2.x), mk3(n2.y, n2.z, n2.w), o, inv, lim, tn1);
+            if (h0 && h1) {
+                bool swap = tn1 < tn0;
+                int farc = swap ? c0 : c1;
+                node = swap ? c1 : c0;
+                if (sp < VRT_LDS_STACK) my_lds[sp * VRT_STACK_LANES] = farc;
+                else if (sp < VRT_BVH_STACK) deep[sp - VRT_LDS_STACK] = farc;
+                sp++;
+                pop = false;
+            } else if (h0 || h1) {
+                node = h0 ? c0 : c1;
+                pop = false;
+            }
         } else {
+            int id = ~node;
+            if (id != skip) test_prim(S, id, o, d, maxd, best);
+            if (ANY && best.prim >= 0) { if (best.t < tlim) return best; best.prim = -1; best.t = INFINITY; }
+        }
+        if (pop) {
             if (sp == 0) break;
-            node = stack[--sp];
+            --sp;
+            node = sp < VRT_LDS_STACK ? my_lds[sp * VRT_STACK_LANES] : deep[sp - VRT_LDS_STACK];
         }
     }
     return best;

@@ -12,6 +12,7 @@
 //   k_wf_resolve  after the last sample: average, tone-map, write the framebuffer.
 // Samples are traced one after the other so that the per-pixel sum is formed in sample order
 // (RayTracerUnity.cs:580-592).
+#define VRT_STACK_LANES 256
 #include "vrt_trace.h"
 #include "vrt_launch.h"
 
