@@ -226,6 +226,18 @@ def main():
             "ms_per_frame_kernel": kernel_ms,
             "roofline": roof,
         }
+        if world == 1:
+            # the boundary with host buffers (vrt_render): render + PCIe read-back into pageable
+            # memory; reported for reference only, never as `value`
+            hp = ra.Params(offsets=offsets, mode=mode, **kw)
+            h_rgba = np.zeros((H, W, 4), np.float32)
+            h_hit = np.zeros((H, W), np.int32)
+            ctx.render(hp, rgba=h_rgba, hit=h_hit)
+            t0 = time.perf_counter()
+            for _ in range(3):
+                ctx.render(hp, rgba=h_rgba, hit=h_hit)
+            host_ms = (time.perf_counter() - t0) * 1e3 / 3
+            out["host_buffer_path"] = {"ms_per_frame": host_ms, "Mrays_per_s": queries / host_ms / 1e3}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(scene, cam, prm)
             out["gpu_over_cpu_serial"] = out["value"] / out["cpu_baseline"]["value"]
