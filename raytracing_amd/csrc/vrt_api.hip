@@ -185,7 +185,9 @@ extern "C" int vrt_set_scene(vrt_ctx* c, const vrt_scene_desc* d)
         box[4 * i + 0] = make_float4(b.center[0], b.center[1], b.center[2], b.half[0]);
         box[4 * i + 1] = make_float4(b.axis[0], b.axis[1], b.axis[2], b.half[1]);
         box[4 * i + 2] = make_float4(b.axis[3], b.axis[4], b.axis[5], b.half[2]);
-        box[4 * i + 3] = make_float4(b.axis[6], b.axis[7], b.axis[8], 0.f);
+        // .w = squared circumradius, inflated; used by the brute-force loop's conservative cull
+        double r2 = ((double)b.half[0] * b.half[0] + (double)b.half[1] * b.half[1] + (double)b.half[2] * b.half[2]) * 1.001;
+        box[4 * i + 3] = make_float4(b.axis[6], b.axis[7], b.axis[8], (float)r2);
         pm[d->n_spheres + i] = b.material;
     }
     for (uint32_t i = 0; i < d->n_triangles; ++i) {

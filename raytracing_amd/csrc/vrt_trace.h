@@ -160,6 +160,15 @@ __device__ __forceinline__ Hit intersect_brute(const DevScene& S, f3 o, f3 d, fl
     for (int i = 0; i < S.n_box; ++i) {
         float t; int aux;
         const float4* b = S.box + 4 * i;
+        // Conservative cull: b[3].w = squared circumradius of the box.  A ray that clears the
+        // circumsphere (with 32 ulp of |oc|^2 slack for rounding) cannot touch the box; when
+        // no lane of the wave can, the slab test with its three divisions is skipped.
+        float4 bc = b[0];
+        f3 oc = o - xyz(bc);
+        float oo = dot3(oc, oc), bb = dot3(oc, d);
+        float cs = oo - b[3].w, slack = 4e-6f * oo;
+        bool may = !((bb * bb - cs + slack < 0.f) || (cs > slack && bb > 0.f));
+        if (!__any(may)) continue;
         if (i + S.n_sph != skip && hit_box(b[0], b[1], b[2], b[3], o, d, maxd, t, aux) && t < best.t && t < tlim) {
             best.t = t; best.prim = i + S.n_sph; best.aux = aux;
             if (ANY) return best;
