@@ -138,3 +138,16 @@ def ao_direction(n):
 
 def pixel_set(seed, pixel, n_sets):
     return lib().vrto_pixel_set(seed, pixel, n_sets)
+
+
+def trace_pixels(scene, cam, params, pixels):
+    """Oracle result for a list of linear pixel indices: (rgba[n,4], hit[n], rays[6])."""
+    d = scene.desc()
+    px = np.ascontiguousarray(pixels, np.int32)
+    rgba = np.zeros((len(px), 4), np.float32)
+    hit = np.zeros(len(px), np.int32)
+    rays = np.zeros(abi.VRT_RAY_CLASSES, np.uint64)
+    lib().vrto_trace_pixels(C.byref(d), C.byref(cam), C.byref(params), len(px),
+                            C.c_void_p(px.ctypes.data), C.c_void_p(rgba.ctypes.data),
+                            C.c_void_p(hit.ctypes.data), C.c_void_p(rays.ctypes.data))
+    return rgba, hit, rays

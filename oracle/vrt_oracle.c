@@ -866,3 +866,34 @@ int vrto_sampler_table(int sampler, int n, int sets, float hStep, float vStep, u
     free(sx); free(sy); free(shuf); free(idx);
     return 0;
 }
+
+/* A list of pixels of one frame (linear index h*width+v): scene set-up once, then the
+ * per-pixel routine for each.  Used to spot-check full-size frames. */
+int vrto_trace_pixels(const vrt_scene_desc* scene, const vrt_camera* cam, const vrt_params* prm,
+                      int n, const int32_t* pixels, float* rgba, int32_t* hit_id, uint64_t* rays_out)
+{
+    oscene s; scene_init(&s, scene);
+    uint64_t tot[VRT_RAY_CLASSES] = {0};
+#ifdef _OPENMP
+#pragma omp parallel
+#endif
+    {
+        octx c; memset(&c, 0, sizeof c); c.scene = &s; c.prm = prm;
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 16)
+#endif
+        for (int i = 0; i < n; ++i) {
+            int32_t id;
+            col px = trace_pixel(&c, cam, pixels[i] / cam->width, pixels[i] % cam->width, -1, &id);
+            rgba[4 * i] = px.r; rgba[4 * i + 1] = px.g; rgba[4 * i + 2] = px.b; rgba[4 * i + 3] = px.a;
+            hit_id[i] = id;
+        }
+#ifdef _OPENMP
+#pragma omp critical
+#endif
+        for (int k = 0; k < VRT_RAY_CLASSES; ++k) tot[k] += c.rays[k];
+    }
+    if (rays_out) memcpy(rays_out, tot, sizeof tot);
+    scene_free(&s);
+    return 0;
+}

@@ -1,0 +1,106 @@
+"""Full-size frames of the benchmark configurations on the GPU.  The oracle cannot render these
+in seconds, so they are checked through size-independent properties and on a random sample of
+pixels traced by the oracle."""
+import numpy as np
+import pytest
+
+import raytracing_amd as ra
+from raytracing_amd import abi, host
+
+pytestmark = pytest.mark.gpu
+
+
+def _sample_check(oracle_mod, scene, cam, prm, rgba, hit, n=1500, seed=0):
+    rng = np.random.default_rng(seed)
+    px = rng.integers(0, cam.width * cam.height, n).astype(np.int32)
+    o_rgba, o_hit, _ = oracle_mod.trace_pixels(scene, cam, prm.c, px)
+    g_rgba = rgba.reshape(-1, 4)[px]
+    g_hit = hit.reshape(-1)[px]
+    assert np.array_equal(g_hit, o_hit), f"{np.count_nonzero(g_hit != o_hit)} of {n} sampled hit ids differ"
+    both_nan = np.isnan(g_rgba) & np.isnan(o_rgba)
+    err = np.abs(np.where(both_nan, 0, g_rgba) - np.where(both_nan, 0, o_rgba))
+    assert not np.isnan(err).any()
+    assert err.max() <= 1.0 / 255.0, err.max()
+
+
+def _properties(ctx, scene, cam, kw, offsets=None):
+    ctx.set_scene(scene)
+    ctx.set_camera(cam)
+    H, W = cam.height, cam.width
+    prm = ra.Params(offsets=offsets, **kw)
+    rgba, hit, st = ctx.render(prm)
+    rays = list(st.rays)
+    spp = kw.get("spp", 1)
+    assert rays[abi.VRT_RAY_PRECHECK] == H * W * spp
+    if spp == 1:
+        assert rays[abi.VRT_RAY_PRIMARY] == np.count_nonzero(hit >= 0)
+        assert np.all(rgba[hit < 0][:, :3] == 0)          # primary misses are black
+    assert rays[abi.VRT_RAY_AO] <= rays[abi.VRT_RAY_PRIMARY] + rays[abi.VRT_RAY_REFLECT]
+    assert np.all(rgba[..., :3][~np.isnan(rgba[..., :3])] <= 1.0)  # tone-mapped
+    # determinism
+    rgba2, hit2, st2 = ctx.render(prm)
+    assert np.array_equal(rgba, rgba2, equal_nan=True) and np.array_equal(hit, hit2)
+    assert list(st2.rays) == rays
+    # strips rendered separately (as 4 ranks would) reassemble to the same frame
+    acc = np.zeros_like(rgba)
+    acc_hit = np.full_like(hit, -9)
+    tot = np.zeros(6, np.int64)
+    for k in range(4):
+        _, _, s = ctx.render(ra.Params(offsets=offsets, tile_index=k, tile_count=4, tile_rows=8, **kw), rgba=acc, hit=acc_hit)
+        tot += np.array(s.rays[:], np.int64)
+    assert np.array_equal(acc, rgba, equal_nan=True) and np.array_equal(acc_hit, hit)
+    assert tot.tolist() == rays
+    return prm, rgba, hit, st
+
+
+def test_c2_teaching_1080p(vrt_ctx, oracle_mod):
+    scene, cam = ra.teaching_scene(), ra.teaching_camera(1920, 1080)
+    kw = dict(spp=1, max_depth=5)
+    prm, rgba, hit, st = _properties(vrt_ctx, scene, cam, kw)
+    _sample_check(oracle_mod, scene, cam, prm, rgba, hit, n=4000)
+    wf, wf_hit, wst = vrt_ctx.render(ra.Params(mode=abi.VRT_MODE_WAVEFRONT, **kw))
+    assert np.array_equal(wf, rgba, equal_nan=True) and np.array_equal(wf_hit, hit)
+    assert list(wst.rays) == list(st.rays)
+    # single-pixel entry point agrees with the frame
+    for (h, v) in [(540, 960), (0, 0), (1079, 1919), (300, 1200)]:
+        c, id_, _, _ = vrt_ctx.trace_pixel(prm, h, v, cap=0)
+        assert id_ == hit[h, v] and np.array_equal(c, rgba[h, v], equal_nan=True)
+
+
+def test_c3_ten_thousand_spheres_4k(vrt_ctx, oracle_mod):
+    scene, cam = ra.random_spheres_scene(10000), ra.random_spheres_camera(3840, 2160)
+    offs = host.sampler_table(abi.VRT_SAMPLER_JITTERED, 4, 83, 2.4 * (16 / 9) / 3840, 2.4 / 2160, seed=1)
+    kw = dict(spp=4, max_depth=8, rng=200.0, seed=1)
+    prm, rgba, hit, st = _properties(vrt_ctx, scene, cam, kw, offsets=offs)
+    _sample_check(oracle_mod, scene, cam, prm, rgba, hit, n=1500)
+    assert st.bvh_nodes == scene.n_prims - 1
+
+
+def test_c4_million_triangles_1080p(vrt_ctx, oracle_mod):
+    scene, cam = ra.tessellated_mesh_scene(708), ra.tessellated_mesh_camera(1920, 1080)
+    assert len(scene.indices) >= 1_000_000
+    kw = dict(spp=1, max_depth=5, rng=100.0)
+    prm, rgba, hit, st = _properties(vrt_ctx, scene, cam, kw)
+    _sample_check(oracle_mod, scene, cam, prm, rgba, hit, n=1500)
+
+
+def test_record_mode_bounded_pixel_set(vrt_ctx, oracle_mod):
+    """vrt_render with a list of pixels to record: the segments of each listed pixel equal the
+    oracle's ray tree; capacity overflow is reported through the count."""
+    scene, cam = ra.teaching_scene(), ra.teaching_camera(1920, 1080)
+    vrt_ctx.set_scene(scene)
+    vrt_ctx.set_camera(cam)
+    rng = np.random.default_rng(5)
+    px = rng.integers(0, 1920 * 1080, 256).astype(np.int32)
+    prm = ra.Params(spp=1, max_depth=5)
+    segs, counts = prm.record(px, cap=8)
+    vrt_ctx.render(prm)
+    assert counts.max() > 8  # some mirror paths need more than 8 segments
+    for i in range(0, 256, 8):
+        h, v = divmod(int(px[i]), 1920)
+        _, _, o_segs, o_n, _ = oracle_mod.trace_pixel(scene, cam, ra.Params(spp=1, max_depth=5).c, h, v, -1, 8)
+        assert counts[i] == o_n
+        for j in range(min(o_n, 8)):
+            a, b = segs[i * 8 + j], o_segs[j]
+            assert (a.kind, a.depth, a.hit_prim) == (b.kind, b.depth, b.hit_prim)
+            assert list(a.origin) == list(b.origin) and list(a.end) == list(b.end)
