@@ -60,6 +60,13 @@ def build_workload(name, n_gpus):
         offsets = host.sampler_table(abi.VRT_SAMPLER_JITTERED, 4, 83, 2.0 * (w / h) / w, 2.0 / h, seed=1)
         kw = dict(spp=4, max_depth=5, rng=100.0, seed=1)
         label = f"1M-triangle mesh {w}x{h}, 4 spp jittered, depth 5"
+    elif name == "c5":
+        w, h = (7680, 4320)
+        scene = ra.random_spheres_scene(10000)
+        cam = ra.random_spheres_camera(w, h)
+        offsets = host.sampler_table(abi.VRT_SAMPLER_JITTERED, 64, 83, 2.4 * (w / h) / w, 2.4 / h, seed=1)
+        kw = dict(spp=64, max_depth=8, rng=200.0, seed=1)
+        label = f"10k random spheres {w}x{h}, 64 spp jittered, depth 8"
     else:
         raise SystemExit(f"unknown workload {name}")
     return scene, cam, offsets, kw, label
@@ -108,6 +115,11 @@ def main():
     ap.add_argument("--workload", default="c2")
     ap.add_argument("--mode", default="auto", choices=["auto", "mega", "wavefront"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--emulate-ranks", type=int, default=0,
+                    help="on one GPU: time each rank's strips of an N-way split of the workload's own "
+                         "frame one after the other (strong-scaling load balance without N GPUs)")
+    ap.add_argument("--tile-rows", type=int, default=8, help="rows per strip of the multi-GPU split")
+    ap.add_argument("--record", type=int, default=0, help="also record the ray tree of this many pixels")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -126,14 +138,14 @@ def main():
 
     scene, cam, offsets, kw, label = build_workload(args.workload, world)
     mode = {"auto": abi.VRT_MODE_AUTO, "mega": abi.VRT_MODE_MEGAKERNEL, "wavefront": abi.VRT_MODE_WAVEFRONT}[args.mode]
-    prm = ra.Params(offsets=offsets, mode=mode, tile_index=rank, tile_count=world, tile_rows=8,
+    prm = ra.Params(offsets=offsets, mode=mode, tile_index=rank, tile_count=world, tile_rows=args.tile_rows,
                     compact_rows=True, **kw)
     ctx = host.Context(local_rank)
     ctx.set_scene(scene)
     ctx.set_camera(cam)
 
     W, H = cam.width, cam.height
-    fg = tiles.FrameGather(H, W, 4, world, rank, 8, dev)
+    fg = tiles.FrameGather(H, W, 4, world, rank, args.tile_rows, dev)
     local = fg.local
     local_hit = torch.empty((fg.rows_max, W), dtype=torch.int32, device=dev)
     stream = torch.cuda.current_stream()
@@ -238,6 +250,37 @@ def main():
                 ctx.render(hp, rgba=h_rgba, hit=h_hit)
             host_ms = (time.perf_counter() - t0) * 1e3 / 3
             out["host_buffer_path"] = {"ms_per_frame": host_ms, "Mrays_per_s": queries / host_ms / 1e3}
+        if world == 1 and args.emulate_ranks > 1:
+            n = args.emulate_ranks
+            per_rank, per_rank_rays = [], []
+            for k in range(n):
+                rp = ra.Params(offsets=offsets, mode=mode, tile_index=k, tile_count=n, tile_rows=args.tile_rows,
+                               compact_rows=True, **kw)
+                ctx.render_device(rp, local.data_ptr(), local_hit.data_ptr(), stream.cuda_stream)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                for _ in range(max(args.steps, 1)):
+                    ctx.render_device(rp, local.data_ptr(), local_hit.data_ptr(), stream.cuda_stream)
+                e1.record(stream)
+                torch.cuda.synchronize()
+                per_rank.append(e0.elapsed_time(e1) / max(args.steps, 1))
+                per_rank_rays.append(int(sum(ctx.fetch_stats().rays[1:])))
+            out["emulated_strong_scaling"] = {
+                "ranks": n, "ms_per_rank": per_rank, "rays_per_rank": per_rank_rays,
+                "one_gpu_full_frame_ms": kernel_ms,
+                "predicted_parallel_efficiency_render_only": kernel_ms / (n * max(per_rank)),
+                "note": "each rank's strips rendered alone on this GPU; excludes the RCCL gather"}
+        if world == 1 and args.record > 0:
+            rng = np.random.default_rng(0)
+            px = rng.integers(0, W * H, args.record).astype(np.int32)
+            rp = ra.Params(offsets=offsets, mode=mode, **kw)
+            segs, counts = rp.record(px, cap=64)
+            t0 = time.perf_counter()
+            ctx.render(rp, rgba=h_rgba, hit=h_hit)
+            out["record_mode"] = {"pixels": int(args.record), "cap": 64, "segments": int(counts.sum()),
+                                  "overflowed_pixels": int((counts > 64).sum()),
+                                  "frame_plus_records_ms": (time.perf_counter() - t0) * 1e3}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(scene, cam, prm)
             out["gpu_over_cpu_serial"] = out["value"] / out["cpu_baseline"]["value"]
