@@ -41,15 +41,19 @@ __device__ __forceinline__ void flush_counters(const Counters& C, unsigned long 
 
 // ------------------------------------------------------------------ megakernel
 
-// Block = 256 lanes = 4 waves; each wave owns an 8x8 pixel tile (coherent rays, and eight
-// full 128-byte framebuffer lines per wave store); a block covers 32x8 pixels.
-// Blocks are renumbered so that the 8 blocks dealt round-robin to the 8 XCDs come from 8
-// separate bands of the image and each XCD's L2 keeps seeing neighbouring tiles.
+// Block = VRT_MEGA_THREADS lanes; each wave owns an 8x8 pixel tile (coherent rays, and eight
+// full 128-byte framebuffer lines per wave store).  One wave per block measured 6 % faster
+// than four (finer-grained tail).
+// The BVH variant is latency bound (50-60 % of wave cycles in s_waitcnt): capping it at 96 VGPRs
+// for 5 waves per SIMD measured +18 % (10k spheres) / +8 % (1M triangles) despite some spills;
+// 6 and 8 waves spill too much.  The brute-force variant is faster unconstrained (4 waves).
+// P.xcd_remap (off by default, see vrt_api.hip) renumbers blocks so that the 8 blocks dealt
+// round-robin to the 8 XCDs come from 8 separate bands of the image.
 #ifndef VRT_MEGA_THREADS
 #define VRT_MEGA_THREADS 64
 #endif
 template <bool BVH, bool TWOCHILD>
-__global__ __launch_bounds__(VRT_MEGA_THREADS) void k_mega(DevScene S, DevCam cam, DevParams P, float4* __restrict__ rgba,
+__global__ __launch_bounds__(VRT_MEGA_THREADS, BVH ? 5 : 1) void k_mega(DevScene S, DevCam cam, DevParams P, float4* __restrict__ rgba,
                                               int* __restrict__ hit_id, unsigned long long* ctr,
                                               int blocks_x, int n_blocks)
 {
