@@ -131,10 +131,17 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if os.environ.get("VRT_BENCH_ONE_GPU"):  # rehearsal of the multi-rank code path on a one-GPU box
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    rehearsal = bool(os.environ.get("VRT_BENCH_ONE_GPU")) and world > 1
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:  # RCCL refuses two ranks on one GPU: gloo over host copies, control flow only
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+    cdev = torch.device("cpu") if rehearsal else dev
 
     scene, cam, offsets, kw, label = build_workload(args.workload, world)
     mode = {"auto": abi.VRT_MODE_AUTO, "mega": abi.VRT_MODE_MEGAKERNEL, "wavefront": abi.VRT_MODE_WAVEFRONT}[args.mode]
@@ -145,19 +152,54 @@ def main():
     ctx.set_camera(cam)
 
     W, H = cam.width, cam.height
-    fg = tiles.FrameGather(H, W, 4, world, rank, args.tile_rows, dev)
-    local = fg.local
+    # two frame buffers: while frame k is being gathered (RCCL, its own stream) frame k+1 renders
+    fgs = [tiles.FrameGather(H, W, 4, world, rank, args.tile_rows, cdev) for _ in range(2 if world > 1 else 1)]
+    fg = fgs[0]
+    local = fg.local if not rehearsal else torch.empty_like(fg.local, device=dev)
     local_hit = torch.empty((fg.rows_max, W), dtype=torch.int32, device=dev)
     stream = torch.cuda.current_stream()
+    pending = [None, None]
+    frame_no = [0]
 
     def step():
-        ctx.render_device(prm, local.data_ptr(), local_hit.data_ptr(), stream.cuda_stream)
+        k = frame_no[0] % len(fgs)
+        frame_no[0] += 1
+        if world > 1 and pending[k] is not None:
+            fgs[k].finish(pending[k])  # frame k-2: wait for its gather, de-interleave on rank 0
+            pending[k] = None
+        target = local if rehearsal else fgs[k].local
+        ctx.render_device(prm, target.data_ptr(), local_hit.data_ptr(), stream.cuda_stream)
+        if rehearsal:
+            fgs[k].local.copy_(local)
         if world > 1:
-            fg.gather()  # RCCL gather of the packed strips to rank 0 + de-interleave there
+            pending[k] = fgs[k].gather_async()  # RCCL gather of the packed strips to rank 0
+
+    def drain():
+        for k in range(len(fgs)):
+            if pending[k] is not None:
+                fgs[k].finish(pending[k])
+                pending[k] = None
 
     for _ in range(args.warmup):
         step()
+    drain()
     torch.cuda.synchronize()
+    frames_match = None
+    if world > 1:
+        # once, outside the timed region: the gathered frame must equal the frame one GPU renders alone
+        step()
+        drain()
+        torch.cuda.synchronize()
+        if rank == 0:
+            whole = torch.empty((H, W, 4), dtype=torch.float32, device=dev)
+            wp = ra.Params(offsets=offsets, mode=mode, **kw)
+            ctx.render_device(wp, whole.data_ptr(), None, stream.cuda_stream)
+            torch.cuda.synchronize()
+            got = fgs[(frame_no[0] - 1) % len(fgs)].final.to(dev)
+            frames_match = bool(torch.equal(torch.nan_to_num(got), torch.nan_to_num(whole)))
+            del whole, got
+        ctx.render_device(prm, (local if rehearsal else fgs[0].local).data_ptr(), local_hit.data_ptr(), stream.cuda_stream)
+        torch.cuda.synchronize()
     st = ctx.fetch_stats()
     rays = np.array(st.rays[:], np.int64)
     my_queries = int(rays[1:].sum())
@@ -177,13 +219,14 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
 
-    tot = torch.tensor([elapsed, float(my_queries)], dtype=torch.float64, device=dev)
+    tot = torch.tensor([elapsed, float(my_queries)], dtype=torch.float64, device=cdev)
     if world > 1:
         mx = tot.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
@@ -233,11 +276,13 @@ def main():
             "data": "synthetic",
             "config": {"workload": label, "frame": [W, H], "rays_per_frame": queries,
                        "mode": "wavefront" if st.mode_used == abi.VRT_MODE_WAVEFRONT else "megakernel",
-                       "gather": "rccl gather to rank 0" if world > 1 else "none",
+                       "gather": "rccl gather to rank 0, overlapped with the next frame" if world > 1 else "none",
                        "rays_by_class": {n: int(r) for n, r in zip(abi.RAY_CLASS_NAMES, rays)}},
             "ms_per_frame_kernel": kernel_ms,
             "roofline": roof,
         }
+        if frames_match is not None:
+            out["gathered_frame_equals_single_gpu_frame"] = frames_match
         if world == 1:
             # the boundary with host buffers (vrt_render): render + PCIe read-back into pageable
             # memory; reported for reference only, never as `value`

@@ -65,3 +65,26 @@ class FrameGather:
             return self.final
         dist.gather(self.local, None, dst=0, group=self.group)
         return None
+
+    # ---- pipelined form: the gather of frame k runs on the collective's own stream while the
+    # caller renders frame k+1 into another FrameGather's buffer.
+
+    def gather_async(self):
+        """Starts the gather of `local` (after the work already enqueued on the current stream)
+        and returns a handle for finish().  With world == 1 there is nothing to move."""
+        if self.world <= 1:
+            return None
+        outs = list(self.gathered.unbind(0)) if self.rank == 0 else None
+        return dist.gather(self.local, outs, dst=0, group=self.group, async_op=True)
+
+    def finish(self, handle):
+        """Makes the current stream wait for the gather and, on rank 0, puts the strips in row
+        order.  After it returns `local` may be overwritten by work on the current stream."""
+        if self.world <= 1:
+            return self.final
+        handle.wait()
+        if self.rank == 0:
+            flat = self.gathered.view(self.world * self.rows_max, self.w, self.c)
+            self.final.index_copy_(0, self.dst_index, flat.index_select(0, self.src_index))
+            return self.final
+        return None

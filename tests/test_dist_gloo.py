@@ -41,6 +41,11 @@ def _worker(rank, world, port, height, width, tile_rows, out_path):
     total = torch.tensor([float(rays[1:].sum())], dtype=torch.float64)
     dist.all_reduce(total)
     final = fg.gather()
+    # the pipelined form must give the same frame
+    h = fg.gather_async()
+    final2 = fg.finish(h)
+    if rank == 0:
+        assert torch.equal(final, final2)
     if rank == 0:
         np.save(out_path, final.numpy())
         np.save(out_path + ".rays.npy", total.numpy())
