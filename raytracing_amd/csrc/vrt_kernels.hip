@@ -69,8 +69,10 @@ __global__ __launch_bounds__(VRT_MEGA_THREADS, BVH ? 5 : 1) void k_mega(DevScene
     int h = local_to_global_row(P, r);
     Counters C = {0, 0, 0, 0, 0, 0};
     Recorder R; R.segs = nullptr; R.cap = 0; R.n = 0; R.sample = 0;
+#if VRT_USE_SM
     __shared__ LdsScene s_scene;
     stage_scene(S, &s_scene);
+#endif
     if (v < cam.width && r < P.local_rows && h < cam.height) {
         int id;
 #if VRT_USE_SM
@@ -86,6 +88,10 @@ __global__ __launch_bounds__(VRT_MEGA_THREADS, BVH ? 5 : 1) void k_mega(DevScene
 }
 
 // ------------------------------------------------------------------ recorded pixels
+
+// This kernel always runs the single-loop state-machine tracer (trace_pixel_sm) while k_mega
+// defaults to the straight-line one, so every test run checks both against the oracle and
+// against each other (vrt_trace_pixel must reproduce the frame's pixel bit for bit).
 
 template <bool BVH, bool TWOCHILD>
 __global__ __launch_bounds__(64) void k_pixels(DevScene S, DevCam cam, DevParams P, const int* __restrict__ pixels,
