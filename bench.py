@@ -107,6 +107,86 @@ def cpu_baseline(scene, cam, prm):
             "omp_value": q / (t2 - t1) / 1e6, "omp_cores": nthr}
 
 
+def scaling_8k(local_rank, world, rank, dev, cdev, rehearsal, frames, tile_rows, mode):
+    """The configuration the scaling target is stated on: 10k random spheres at 7680x4320,
+    64 samples per pixel, depth 8, ONE frame of fixed size split into 8-row strips over the
+    ranks (strong scaling) and gathered to rank 0 with RCCL.  Timed like the main loop: barrier
+    and device synchronisation on both sides, maximum over ranks.  Returns a dict on rank 0."""
+    scene, cam, offsets, kw, label = build_workload("c5", world)
+    W, H = cam.width, cam.height
+    ctx = host.Context(local_rank)
+    ctx.set_scene(scene)
+    ctx.set_camera(cam)
+    prm = ra.Params(offsets=offsets, mode=mode, tile_index=rank, tile_count=world, tile_rows=tile_rows,
+                    compact_rows=True, **kw)
+    fg = tiles.FrameGather(H, W, 4, world, rank, tile_rows, cdev)
+    local = fg.local if not rehearsal else torch.empty_like(fg.local, device=dev)
+    stream = torch.cuda.current_stream()
+
+    def frame():
+        ctx.render_device(prm, local.data_ptr(), None, stream.cuda_stream)
+        if rehearsal:
+            fg.local.copy_(local)
+        return fg.gather()
+
+    # warm-up at 1 sample per pixel (same kernels, same gather), then the timed full-cost frames
+    wprm = ra.Params(offsets=np.ascontiguousarray(offsets[:, :1]), mode=mode, tile_index=rank, tile_count=world, tile_rows=tile_rows,
+                     compact_rows=True, **dict(kw, spp=1))
+    ctx.render_device(wprm, local.data_ptr(), None, stream.cuda_stream)
+    fg.gather()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(frames):
+        final = frame()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    my_q = float(sum(int(r) for r in ctx.fetch_stats().rays[1:]))
+    # render-only time of this rank's strips (events on the launch stream)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    ctx.render_device(prm, local.data_ptr(), None, stream.cuda_stream)
+    e1.record(stream)
+    torch.cuda.synchronize()
+    render_ms = e0.elapsed_time(e1)
+    tot = torch.tensor([elapsed, render_ms, my_q], dtype=torch.float64, device=cdev)
+    if world > 1:
+        mx = tot.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = tot.clone()
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        elapsed, render_ms, queries = float(mx[0]), float(mx[1]), float(sm[2])
+    else:
+        queries = my_q
+    out = None
+    if rank == 0:
+        out = {"workload": label, "scaling": "strong", "frames": frames, "frame": [W, H],
+               "rays_per_frame": queries, "ms_per_frame": elapsed * 1e3 / frames,
+               "value": queries * frames / elapsed / 1e6, "unit": "Mrays/s",
+               "slowest_rank_render_ms": render_ms,
+               "gather": "rccl gather of the packed strips to rank 0 + de-interleave, inside the timed region"
+                         if world > 1 else "none",
+               "note": "parallel efficiency at N GPUs = value(N) / (N * value(1)) of this object"}
+        if world > 1:
+            # the gathered frame must equal the frame one GPU renders alone, bit for bit
+            whole = torch.empty((H, W, 4), dtype=torch.float32, device=dev)
+            wp = ra.Params(offsets=offsets, mode=mode, **kw)
+            ctx.render_device(wp, whole.data_ptr(), None, stream.cuda_stream)
+            torch.cuda.synchronize()
+            out["gathered_frame_equals_single_gpu_frame"] = bool(
+                torch.equal(torch.nan_to_num(final.to(dev)), torch.nan_to_num(whole)))
+            del whole
+    if world > 1:
+        dist.barrier()
+    ctx.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -120,6 +200,9 @@ def main():
                          "frame one after the other (strong-scaling load balance without N GPUs)")
     ap.add_argument("--tile-rows", type=int, default=8, help="rows per strip of the multi-GPU split")
     ap.add_argument("--record", type=int, default=0, help="also record the ray tree of this many pixels")
+    ap.add_argument("--frames-8k", type=int, default=2,
+                    help="frames of the 8K x 64 spp strong-scaling measurement reported as `scaling_8k` "
+                         "(0 = skip it)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -236,6 +319,10 @@ def main():
     else:
         queries = float(my_queries)
 
+    s8k = None
+    if args.frames_8k > 0 and args.workload == "c2":
+        s8k = scaling_8k(local_rank, world, rank, dev, cdev, rehearsal, args.frames_8k, args.tile_rows, mode)
+
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
         flops = algorithmic_flops(scene, rays, st.pixels)
@@ -283,6 +370,8 @@ def main():
         }
         if frames_match is not None:
             out["gathered_frame_equals_single_gpu_frame"] = frames_match
+        if s8k is not None:
+            out["scaling_8k"] = s8k
         if world == 1:
             # the boundary with host buffers (vrt_render): render + PCIe read-back into pageable
             # memory; reported for reference only, never as `value`

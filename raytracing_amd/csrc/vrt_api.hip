@@ -19,7 +19,7 @@ struct vrt_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // scene
-    float4 *d_sph = nullptr, *d_box = nullptr, *d_tri = nullptr, *d_mat = nullptr, *d_bvh = nullptr;
+    float4 *d_sph = nullptr, *d_box = nullptr, *d_tri = nullptr, *d_mat = nullptr, *d_bvh = nullptr, *d_bvh4 = nullptr;
     int* d_prim_mat = nullptr;
     DevLight* d_lights = nullptr;
     DevScene scene;
@@ -108,9 +108,9 @@ extern "C" int vrt_create(int device, vrt_ctx** out)
 static void free_scene(vrt_ctx* c)
 {
     hipFree(c->d_sph); hipFree(c->d_box); hipFree(c->d_tri); hipFree(c->d_mat); hipFree(c->d_bvh);
-    hipFree(c->d_prim_mat); hipFree(c->d_lights);
+    hipFree(c->d_bvh4); hipFree(c->d_prim_mat); hipFree(c->d_lights);
     c->d_lights = nullptr;
-    c->d_sph = c->d_box = c->d_tri = c->d_mat = c->d_bvh = nullptr;
+    c->d_sph = c->d_box = c->d_tri = c->d_mat = c->d_bvh = c->d_bvh4 = nullptr;
     c->d_prim_mat = nullptr;
     c->have_scene = false;
 }
@@ -237,8 +237,9 @@ extern "C" int vrt_set_scene(vrt_ctx* c, const vrt_scene_desc* d)
     c->bvh_ms = 0.f; c->bvh_depth = 0;
     if (c->use_bvh) {
         HIPCHK(c, hipMalloc(&c->d_bvh, 4 * (size_t)(n_prims - 1) * sizeof(float4)));
-        S.bvh = c->d_bvh;
-        hipError_t e = vrt_build_lbvh(S, c->d_bvh, &c->bvh_depth, &c->bvh_ms, c->stream);
+        HIPCHK(c, hipMalloc(&c->d_bvh4, 8 * (size_t)(n_prims - 1) * sizeof(float4)));
+        S.bvh = c->d_bvh; S.bvh4 = c->d_bvh4;
+        hipError_t e = vrt_build_lbvh(S, c->d_bvh, c->d_bvh4, &c->bvh_depth, &c->bvh_ms, c->stream);
         if (e != hipSuccess) return fail(c, VRT_ERR_HIP, std::string("LBVH build: ") + hipGetErrorString(e));
         if (c->bvh_depth > VRT_BVH_STACK - 2)
             return fail(c, VRT_ERR_CAPACITY, "LBVH deeper than the traversal stack");

@@ -1,6 +1,7 @@
 // LBVH construction on the device (gfx950): Morton codes of primitive centroids -> radix sort
-// -> Karras' binary radix tree -> bottom-up fit of child boxes.  The output is the 64-byte
-// "two child boxes per node" layout described in vrt_device.h.
+// -> Karras' binary radix tree -> bottom-up fit of child boxes -> collapse of every second
+// level into 4-wide nodes.  The outputs are the 64-byte "two child boxes per node" binary
+// layout and the 128-byte 4-wide layout described in vrt_device.h.
 //
 // Closest-hit results do not depend on the tree (candidates are ranked by (t, id)), so the
 // builder only has to be conservative: primitive boxes are padded by a relative 1e-4.
@@ -212,11 +213,60 @@ __global__ __launch_bounds__(256) void k_depth(int n, const int* __restrict__ pa
     if ((threadIdx.x & 63) == 0) atomicMax(depth, d);
 }
 
+// 4-wide collapse, one lane per binary inner node.  Nodes at even depth survive and adopt
+// their grandchildren (a leaf child is adopted as it is); nodes at odd depth are absorbed.  A
+// surviving node keeps its binary index, so child codes need no translation.
+__global__ __launch_bounds__(256) void k_collapse4(int n_inner, const float4* __restrict__ nodes,
+                                                   const int* __restrict__ parent, float4* __restrict__ wide)
+{
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_inner) return;
+    int depth = 0;
+    for (int p = parent[i]; p >= 0 && depth < 4096; p = parent[p]) ++depth;
+    if (depth & 1) return;
+    float lo[4][3], hi[4][3];
+    int code[4];
+    int m = 0;
+    const float4* nd = nodes + 4 * (size_t)i;
+    float4 a0 = nd[0], a1 = nd[1], a2 = nd[2], a3 = nd[3];
+    const float blo[2][3] = {{a0.x, a0.y, a0.z}, {a1.z, a1.w, a2.x}};
+    const float bhi[2][3] = {{a0.w, a1.x, a1.y}, {a2.y, a2.z, a2.w}};
+    const int bc[2] = {__float_as_int(a3.x), __float_as_int(a3.y)};
+    for (int side = 0; side < 2; ++side) {
+        if (bc[side] < 0) {
+            for (int k = 0; k < 3; ++k) { lo[m][k] = blo[side][k]; hi[m][k] = bhi[side][k]; }
+            code[m++] = bc[side];
+        } else {
+            const float4* cd = nodes + 4 * (size_t)bc[side];
+            float4 c0 = cd[0], c1 = cd[1], c2 = cd[2], c3 = cd[3];
+            lo[m][0] = c0.x; lo[m][1] = c0.y; lo[m][2] = c0.z; hi[m][0] = c0.w; hi[m][1] = c1.x; hi[m][2] = c1.y;
+            code[m++] = __float_as_int(c3.x);
+            lo[m][0] = c1.z; lo[m][1] = c1.w; lo[m][2] = c2.x; hi[m][0] = c2.y; hi[m][1] = c2.z; hi[m][2] = c2.w;
+            code[m++] = __float_as_int(c3.y);
+        }
+    }
+    for (; m < 4; ++m) {
+        for (int k = 0; k < 3; ++k) { lo[m][k] = INFINITY; hi[m][k] = -INFINITY; }
+        code[m] = VRT_BVH4_EMPTY;
+    }
+    float4* w = wide + 8 * (size_t)i;
+    w[0] = make_float4(lo[0][0], lo[1][0], lo[2][0], lo[3][0]);
+    w[1] = make_float4(lo[0][1], lo[1][1], lo[2][1], lo[3][1]);
+    w[2] = make_float4(lo[0][2], lo[1][2], lo[2][2], lo[3][2]);
+    w[3] = make_float4(hi[0][0], hi[1][0], hi[2][0], hi[3][0]);
+    w[4] = make_float4(hi[0][1], hi[1][1], hi[2][1], hi[3][1]);
+    w[5] = make_float4(hi[0][2], hi[1][2], hi[2][2], hi[3][2]);
+    w[6] = make_float4(__int_as_float(code[0]), __int_as_float(code[1]), __int_as_float(code[2]),
+                       __int_as_float(code[3]));
+    w[7] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 } // namespace
 
 #define BCHK(expr) do { e = (expr); if (e != hipSuccess) goto done; } while (0)
 
-hipError_t vrt_build_lbvh(const DevScene& S, float4* nodes, int* depth_out, float* ms_out, hipStream_t stream)
+hipError_t vrt_build_lbvh(const DevScene& S, float4* nodes, float4* wide, int* depth_out, float* ms_out,
+                          hipStream_t stream)
 {
     const int n = S.n_prims;
     hipError_t e = hipSuccess;
@@ -256,6 +306,7 @@ hipError_t vrt_build_lbvh(const DevScene& S, float4* nodes, int* depth_out, floa
     hipLaunchKernelGGL(k_fit, dim3(blocks), dim3(256), 0, stream, n, vals2, pbox, child, parent, leaf_parent, arrived,
                        parked, nodes);
     hipLaunchKernelGGL(k_depth, dim3(blocks), dim3(256), 0, stream, n, parent, leaf_parent, depth);
+    hipLaunchKernelGGL(k_collapse4, dim3((n - 1 + 255) / 256), dim3(256), 0, stream, n - 1, nodes, parent, wide);
     BCHK(hipEventRecord(e1, stream));
     BCHK(hipGetLastError());
     BCHK(hipStreamSynchronize(stream));

@@ -10,6 +10,11 @@
 //                              boxes of both children:
 //                              (lo0.xyz, hi0.x) (hi0.yz, lo1.xy) (lo1.z, hi1.xyz) (c0, c1, -, -)
 //                              child >= 0: internal node index, child < 0: leaf, primitive = ~child
+//   bvh4  float4[8*(n_prims-1)] the same tree with every second level collapsed: one 128-byte
+//                              node per surviving internal node (index = its binary index)
+//                              holding up to four child boxes, struct of arrays:
+//                              lo.x[4] lo.y[4] lo.z[4] hi.x[4] hi.y[4] hi.z[4] code[4] pad[4];
+//                              code as above, VRT_BVH4_EMPTY for an unused slot
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -32,6 +37,7 @@ struct DevScene {
     const int* prim_mat;
     const float4* mat;
     const float4* bvh;
+    const float4* bvh4;
     int n_lights;
     const DevLight* lights; // n_lights entries in device memory
     vrt_shading sh;
@@ -74,3 +80,5 @@ struct RayQueue {
 #define VRT_QUEUE_ARRAYS 12
 
 #define VRT_BVH_STACK 64
+#define VRT_BVH4_STACK 96
+#define VRT_BVH4_EMPTY ((int)0x80000000)

@@ -29,5 +29,7 @@ hipError_t vrt_launch_wavefront(const DevScene& S, const DevCam& cam, const DevP
                                 unsigned long long* ctr, hipStream_t stream);
 
 // LBVH build on the device.  prim arrays are those of DevScene; writes 4*(n_prims-1) float4
-// nodes to `nodes`.  Returns the tree depth in *depth_out.  Synchronises the stream.
-hipError_t vrt_build_lbvh(const DevScene& S, float4* nodes, int* depth_out, float* ms_out, hipStream_t stream);
+// binary nodes to `nodes` and 8*(n_prims-1) float4 of 4-wide nodes to `wide` (slots of absorbed
+// nodes stay unwritten).  Returns the binary tree depth in *depth_out.  Synchronises the stream.
+hipError_t vrt_build_lbvh(const DevScene& S, float4* nodes, float4* wide, int* depth_out, float* ms_out,
+                          hipStream_t stream);

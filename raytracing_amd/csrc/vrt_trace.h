@@ -258,11 +258,104 @@ __device__ __forceinline__ Hit intersect_bvh(const DevScene& S, f3 o, f3 d, floa
     return best;
 }
 
+// VRT_BVH4=1 (default) traverses the 4-wide collapse of the LBVH, VRT_BVH4=0 the binary tree.
+#ifndef VRT_BVH4
+#define VRT_BVH4 1
+#endif
+#define VRT_LDS_STACK4 12
+
+// Orders two (tnear, code) candidates, nearer first.
+__device__ __forceinline__ void order2(float& ta, int& ca, float& tb, int& cb)
+{
+    bool s = tb < ta;
+    float t = s ? tb : ta; tb = s ? ta : tb; ta = t;
+    int c = s ? cb : ca; cb = s ? ca : cb; ca = c;
+}
+
+// Stack-based traversal of the 4-wide tree.  One step loads one 128-byte node and tests its
+// four child boxes; the hit children are visited nearest first, the others wait on the stack
+// as (tnear, code) pairs and are dropped at pop time when a closer hit has been found since.
+// The first VRT_LDS_STACK4 entries of a lane live in LDS ([entry][lane], 8-byte entries,
+// conflict-free), deeper ones in private memory.  As in the binary traversal the result does
+// not depend on the visiting order because candidates are ranked by (t, id).
+__device__ __forceinline__ Hit intersect_bvh4(const DevScene& S, f3 o, f3 d, float maxd, float tlim, int skip, bool ANY)
+{
+    __shared__ unsigned long long lds_stack4[VRT_LDS_STACK4 * VRT_STACK_LANES];
+    unsigned long long* my_lds = lds_stack4 + threadIdx.x;
+    Hit best; best.t = INFINITY; best.prim = -1; best.aux = 0;
+    if (is_zero3(d)) return best;
+    const f3 inv = mk3(1.f / d.x, 1.f / d.y, 1.f / d.z);
+    const float lim0 = fminf(maxd, tlim);
+    unsigned long long deep[VRT_BVH4_STACK - VRT_LDS_STACK4];
+    int sp = 0;
+    int node = 0;
+    bool done = false;
+    // every node is entered at most once; the bound only guards against a corrupt tree
+    for (int guard = 2 * S.n_prims + 8; guard > 0 && !done; --guard) {
+        bool pop = true;
+        if (node >= 0) {
+            const float4* n = S.bvh4 + 8 * (size_t)node;
+            const float4 lx = n[0], ly = n[1], lz = n[2], hx = n[3], hy = n[4], hz = n[5], cc = n[6];
+            const float lim = best.prim >= 0 ? best.t : lim0;
+            int c0 = __float_as_int(cc.x), c1 = __float_as_int(cc.y), c2 = __float_as_int(cc.z), c3 = __float_as_int(cc.w);
+            float t0, t1, t2, t3;
+            bool h0 = slab_test(mk3(lx.x, ly.x, lz.x), mk3(hx.x, hy.x, hz.x), o, inv, lim, t0);
+            bool h1 = slab_test(mk3(lx.y, ly.y, lz.y), mk3(hx.y, hy.y, hz.y), o, inv, lim, t1);
+            bool h2 = slab_test(mk3(lx.z, ly.z, lz.z), mk3(hx.z, hy.z, hz.z), o, inv, lim, t2);
+            bool h3 = slab_test(mk3(lx.w, ly.w, lz.w), mk3(hx.w, hy.w, hz.w), o, inv, lim, t3);
+            t0 = (h0 && c0 != VRT_BVH4_EMPTY) ? t0 : INFINITY;
+            t1 = (h1 && c1 != VRT_BVH4_EMPTY) ? t1 : INFINITY;
+            t2 = (h2 && c2 != VRT_BVH4_EMPTY) ? t2 : INFINITY;
+            t3 = (h3 && c3 != VRT_BVH4_EMPTY) ? t3 : INFINITY;
+            if (!ANY) {
+                order2(t0, c0, t1, c1); order2(t2, c2, t3, c3);
+                order2(t0, c0, t2, c2); order2(t1, c1, t3, c3);
+                order2(t1, c1, t2, c2);
+            } else {
+                // any-hit: order is irrelevant, just move the hits to the front
+                if (!(t0 < INFINITY)) { t0 = t1; c0 = c1; t1 = INFINITY; }
+                if (!(t0 < INFINITY)) { t0 = t2; c0 = c2; t2 = INFINITY; }
+                if (!(t0 < INFINITY)) { t0 = t3; c0 = c3; t3 = INFINITY; }
+            }
+            if (t0 < INFINITY) {
+                node = c0;
+                pop = false;
+#define VRT_PUSH4(T, C)                                                                              \
+                if (T < INFINITY) {                                                                  \
+                    unsigned long long e_ = ((unsigned long long)__float_as_uint(T) << 32) | (unsigned)(C); \
+                    if (sp < VRT_LDS_STACK4) my_lds[sp * VRT_STACK_LANES] = e_;                      \
+                    else if (sp < VRT_BVH4_STACK) deep[sp - VRT_LDS_STACK4] = e_;                    \
+                    sp++;                                                                            \
+                }
+                VRT_PUSH4(t3, c3)
+                VRT_PUSH4(t2, c2)
+                VRT_PUSH4(t1, c1)
+#undef VRT_PUSH4
+            }
+        } else {
+            int id = ~node;
+            if (id != skip) test_prim(S, id, o, d, maxd, best);
+            if (ANY && best.prim >= 0) { if (best.t < tlim) return best; best.prim = -1; best.t = INFINITY; }
+        }
+        if (pop) {
+            const float lim = best.prim >= 0 ? best.t : lim0;
+            for (;;) {
+                if (sp == 0) { done = true; break; }
+                --sp;
+                unsigned long long e = sp < VRT_LDS_STACK4 ? my_lds[sp * VRT_STACK_LANES]
+                                                          : deep[(sp < VRT_BVH4_STACK ? sp : VRT_BVH4_STACK - 1) - VRT_LDS_STACK4];
+                if (!(__uint_as_float((unsigned)(e >> 32)) > lim)) { node = (int)(unsigned)e; break; }
+            }
+        }
+    }
+    return best;
+}
+
 // Closest hit (ANY = false) or "some hit with t < tlim" (ANY = true) within maxd.
 template <bool BVH, bool ANY>
 __device__ __forceinline__ Hit intersect(const DevScene& S, f3 o, f3 d, float maxd, int skip, float tlim = INFINITY)
 {
-    if (BVH) return intersect_bvh(S, o, d, maxd, tlim, skip, ANY);
+    if (BVH) return VRT_BVH4 ? intersect_bvh4(S, o, d, maxd, tlim, skip, ANY) : intersect_bvh(S, o, d, maxd, tlim, skip, ANY);
     return intersect_brute(S, o, d, maxd, tlim, skip, ANY);
 }
 
@@ -270,7 +363,7 @@ __device__ __forceinline__ Hit intersect(const DevScene& S, f3 o, f3 d, float ma
 template <bool BVH>
 __device__ __forceinline__ Hit intersect_rt(const DevScene& S, f3 o, f3 d, float maxd, int skip, float tlim, bool any)
 {
-    if (BVH) return intersect_bvh(S, o, d, maxd, tlim, skip, any);
+    if (BVH) return VRT_BVH4 ? intersect_bvh4(S, o, d, maxd, tlim, skip, any) : intersect_bvh(S, o, d, maxd, tlim, skip, any);
     return intersect_brute(S, o, d, maxd, tlim, skip, any);
 }
 
