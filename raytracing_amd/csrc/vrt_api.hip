@@ -22,6 +22,8 @@ struct vrt_ctx {
     float4 *d_sph = nullptr, *d_box = nullptr, *d_tri = nullptr, *d_mat = nullptr, *d_bvh = nullptr, *d_bvh4 = nullptr;
     int* d_prim_mat = nullptr;
     DevLight* d_lights = nullptr;
+    float4 *d_aab = nullptr, *d_cam_pre = nullptr;
+    std::vector<float4> h_sph, h_box; // host copies for the camera-origin terms
     DevScene scene;
     bool have_scene = false, use_bvh = false;
     float bvh_ms = 0.f;
@@ -109,6 +111,8 @@ static void free_scene(vrt_ctx* c)
 {
     hipFree(c->d_sph); hipFree(c->d_box); hipFree(c->d_tri); hipFree(c->d_mat); hipFree(c->d_bvh);
     hipFree(c->d_bvh4); hipFree(c->d_prim_mat); hipFree(c->d_lights);
+    hipFree(c->d_aab); hipFree(c->d_cam_pre);
+    c->d_aab = c->d_cam_pre = nullptr;
     c->d_lights = nullptr;
     c->d_sph = c->d_box = c->d_tri = c->d_mat = c->d_bvh = c->d_bvh4 = nullptr;
     c->d_prim_mat = nullptr;
@@ -146,6 +150,53 @@ static hipError_t upload(T** dst, const std::vector<T>& src)
     hipError_t e = hipMalloc(dst, src.size() * sizeof(T));
     if (e != hipSuccess) return e;
     return hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice);
+}
+
+// A box qualifies for the world-axis test when each of its axes is exactly +-e_j.  Returns the
+// code hit_aab() expects (k_0 | k_1<<2 | k_2<<4 | flip_j<<(8+j)) and the half extents in world
+// order, or -1.
+static int aab_code(const vrt_box& b, float hw[3])
+{
+    int code = 0, seen = 0;
+    for (int k = 0; k < 3; ++k) {
+        int j = -1;
+        for (int q = 0; q < 3; ++q) {
+            float v = b.axis[3 * k + q];
+            if (v == 1.f || v == -1.f) { if (j >= 0) return -1; j = q; }
+            else if (v != 0.f) return -1;
+        }
+        if (j < 0 || (seen & (1 << j))) return -1;
+        seen |= 1 << j;
+        code |= k << (2 * j);
+        if (b.axis[3 * k + j] < 0.f) code |= 1 << (8 + j);
+        hw[j] = b.half[k];
+    }
+    return code;
+}
+
+// Terms of the brute-force tests that depend only on the ray origin, for rays leaving the
+// camera: float operations and their order are those of hit_sphere / the box loop.
+static int refresh_cam_pre(vrt_ctx* c)
+{
+    if (!c->have_scene || !c->have_cam || c->use_bvh) return VRT_OK;
+    const DevScene& S = c->scene;
+    std::vector<float4> pre((size_t)S.n_sph + S.n_box);
+    const float ox = c->cam.ox, oy = c->cam.oy, oz = c->cam.oz;
+    for (int i = 0; i < S.n_sph; ++i) {
+        float4 s = c->h_sph[i];
+        float x = ox - s.x, y = oy - s.y, z = oz - s.z;
+        float cc = (x * x + y * y + z * z) - s.w * s.w;
+        pre[i] = make_float4(x, y, z, cc);
+    }
+    for (int i = 0; i < S.n_box; ++i) {
+        float4 b0 = c->h_box[4 * (size_t)i];
+        pre[S.n_sph + i] = make_float4(ox - b0.x, oy - b0.y, oz - b0.z, 0.f);
+    }
+    if (pre.empty()) return VRT_OK;
+    if (!c->d_cam_pre) HIPCHK(c, hipMalloc(&c->d_cam_pre, pre.size() * sizeof(float4)));
+    HIPCHK(c, hipMemcpy(c->d_cam_pre, pre.data(), pre.size() * sizeof(float4), hipMemcpyHostToDevice));
+    c->scene.cam_pre = c->d_cam_pre;
+    return VRT_OK;
 }
 
 extern "C" int vrt_set_scene(vrt_ctx* c, const vrt_scene_desc* d)
@@ -244,8 +295,26 @@ extern "C" int vrt_set_scene(vrt_ctx* c, const vrt_scene_desc* d)
         if (c->bvh_depth > VRT_BVH_STACK - 2)
             return fail(c, VRT_ERR_CAPACITY, "LBVH deeper than the traversal stack");
     }
+    if (!c->use_bvh) {
+        c->h_sph = sph; c->h_box = box;
+        std::vector<float4> aab(2 * (size_t)d->n_boxes);
+        bool all = d->n_boxes > 0;
+        for (uint32_t i = 0; i < d->n_boxes && all; ++i) {
+            float hw[3];
+            int code = aab_code(d->boxes[i], hw);
+            if (code < 0) { all = false; break; }
+            float4 a0 = box[4 * (size_t)i];
+            memcpy(&a0.w, &code, 4);
+            aab[2 * (size_t)i] = a0;
+            aab[2 * (size_t)i + 1] = make_float4(hw[0], hw[1], hw[2], box[4 * (size_t)i + 3].w);
+        }
+        if (all) {
+            HIPCHK(c, upload(&c->d_aab, aab));
+            S.aab = c->d_aab; S.all_aab = 1;
+        }
+    }
     c->have_scene = true;
-    return VRT_OK;
+    return refresh_cam_pre(c);
 }
 
 extern "C" int vrt_set_camera(vrt_ctx* c, const vrt_camera* cam)
@@ -261,7 +330,9 @@ extern "C" int vrt_set_camera(vrt_ctx* c, const vrt_camera* cam)
     d.yx = cam->y_axis[0]; d.yy = cam->y_axis[1]; d.yz = cam->y_axis[2];
     d.width = cam->width; d.height = cam->height;
     c->have_cam = true;
-    return VRT_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipDeviceSynchronize()); // frames in flight still read the old terms
+    return refresh_cam_pre(c);
 }
 
 static int owned_rows(int H, int index, int count, int rows)
@@ -299,6 +370,19 @@ static int prepare(vrt_ctx* c, const vrt_params* p, DevParams* out)
     // keep the hardware's round-robin deal; VRT_XCD_REMAP=1 re-enables the banding for study.
     P.xcd_remap = 0;
     if (const char* e = getenv("VRT_XCD_REMAP")) P.xcd_remap = atoi(e);
+    // Megakernel lane split: the largest power of two <= min(spp, 64) sample lanes per pixel that
+    // leaves at most 15 % of the lane-rounds idle; VRT_SAMPLE_SHIFT overrides it for study.
+    P.sample_shift = 0;
+    for (int sh = 6; sh >= 1; --sh) {
+        int n = 1 << sh;
+        if (n > p->spp) continue;
+        int rounds = (p->spp + n - 1) / n;
+        if ((double)rounds * n <= 1.15 * p->spp) { P.sample_shift = sh; break; }
+    }
+    if (const char* e = getenv("VRT_SAMPLE_SHIFT")) {
+        int sh = atoi(e);
+        if (sh >= 0 && sh <= 6) P.sample_shift = sh;
+    }
     P.offsets = nullptr;
     if (p->offsets) {
         size_t n = (size_t)p->n_sets * p->spp;

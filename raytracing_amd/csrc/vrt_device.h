@@ -38,6 +38,10 @@ struct DevScene {
     const float4* mat;
     const float4* bvh;
     const float4* bvh4;
+    // brute-force scenes only:
+    const float4* aab;     // 2 per box when all_aab: (centre.xyz, face/flip code) (world half extents, r^2)
+    int all_aab;           // every box has signed world axes as its axes
+    const float4* cam_pre; // per sphere (o-c, |o-c|^2 - r^2), per box (o-c, 0) for o = camera origin
     int n_lights;
     const DevLight* lights; // n_lights entries in device memory
     vrt_shading sh;
@@ -63,6 +67,7 @@ struct DevParams {
     int local_rows; // rows this call renders
     int compact;    // outputs indexed by local row instead of global row
     int xcd_remap;  // renumber blocks so that each XCD works on one contiguous band of tiles
+    int sample_shift; // megakernel: log2 of the lanes that share one pixel's samples (0..6)
 };
 
 // Per-call ray counters: 256 slots x 8 words to spread atomic traffic, summed by the host.

@@ -41,19 +41,22 @@ __device__ __forceinline__ void flush_counters(const Counters& C, unsigned long 
 
 // ------------------------------------------------------------------ megakernel
 
-// Block = VRT_MEGA_THREADS lanes; each wave owns an 8x8 pixel tile (coherent rays, and eight
-// full 128-byte framebuffer lines per wave store).  One wave per block measured 6 % faster
-// than four (finer-grained tail).
-// The BVH variant is latency bound (50-60 % of wave cycles in s_waitcnt): capping it at 96 VGPRs
-// for 5 waves per SIMD measured +18 % (10k spheres) / +8 % (1M triangles) despite some spills;
-// 6 and 8 waves spill too much.  The brute-force variant is faster unconstrained (4 waves).
+// Block = one wave.  The 64 lanes are split as (64 >> P.sample_shift) pixels x (1 << P.sample_shift)
+// anti-aliasing samples: with one sample per pixel a wave owns an 8x8 pixel tile (eight full
+// 128-byte framebuffer lines per store); with many samples per pixel the samples of a pixel sit
+// in neighbouring lanes, where they follow almost the same path through the tree and end at the
+// same depth, instead of being looped over by one lane while its neighbours wait for the
+// deepest path of each round.  The per-pixel sum is still formed in sample order
+// (RayTracerUnity.cs:580-592): the lanes' radiances are read back one by one with a wave shuffle.
+// One wave per block measured 6 % faster than four (finer-grained tail).
+// The BVH variant is capped at 96 VGPRs for 5 waves per SIMD (+18 % on 10k spheres, +8 % on 1M
+// triangles despite some spills; 6 and 8 waves spill too much).  The brute-force variant is
+// faster unconstrained (4 waves).
 // P.xcd_remap (off by default, see vrt_api.hip) renumbers blocks so that the 8 blocks dealt
 // round-robin to the 8 XCDs come from 8 separate bands of the image.
-#ifndef VRT_MEGA_THREADS
 #define VRT_MEGA_THREADS 64
-#endif
 template <bool BVH, bool TWOCHILD>
-__global__ __launch_bounds__(VRT_MEGA_THREADS, BVH ? 5 : 1) void k_mega(DevScene S, DevCam cam, DevParams P, float4* __restrict__ rgba,
+__global__ __launch_bounds__(VRT_MEGA_THREADS, BVH ? 5 : 4) void k_mega(DevScene S, DevCam cam, DevParams P, float4* __restrict__ rgba,
                                               int* __restrict__ hit_id, unsigned long long* ctr,
                                               int blocks_x, int n_blocks)
 {
@@ -62,28 +65,72 @@ __global__ __launch_bounds__(VRT_MEGA_THREADS, BVH ? 5 : 1) void k_mega(DevScene
         unsigned q = n_blocks / 8, r = n_blocks % 8, xcd = bid % 8, k = bid / 8;
         if (P.xcd_remap) bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
     }
-    int bx = bid % blocks_x, by = bid / blocks_x;
-    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    int v = bx * (VRT_MEGA_THREADS / 8) + wave * 8 + (lane & 7);
-    int r = by * 8 + (lane >> 3);
-    int h = local_to_global_row(P, r);
+    const int bx = bid % blocks_x, by = bid / blocks_x;
+    const int lane = threadIdx.x;
+#if VRT_USE_SM
+    const int shift = 0;
+#else
+    const int shift = P.sample_shift;
+#endif
+    const int n_sl = 1 << shift;                       // sample lanes per pixel
+    const int pshift = 6 - shift;                      // log2(pixels per wave)
+    const int pw_shift = (pshift + 1) >> 1;            // tile width 2^ceil(pshift/2), height 2^floor(pshift/2)
+    const int pi = lane >> shift, si = lane & (n_sl - 1);
+    const int v = (bx << pw_shift) + (pi & ((1 << pw_shift) - 1));
+    const int r = (by << (pshift - pw_shift)) + (pi >> pw_shift);
+    const int h = local_to_global_row(P, r);
     Counters C = {0, 0, 0, 0, 0, 0};
     Recorder R; R.segs = nullptr; R.cap = 0; R.n = 0; R.sample = 0;
+    const bool inside = v < cam.width && r < P.local_rows && h < cam.height;
 #if VRT_USE_SM
     __shared__ LdsScene s_scene;
     stage_scene(S, &s_scene);
-#endif
-    if (v < cam.width && r < P.local_rows && h < cam.height) {
+    if (inside) {
         int id;
-#if VRT_USE_SM
         float4 c = trace_pixel_sm<BVH, false, TWOCHILD>(S, cam, P, &s_scene, h, v, -1, id, C, R);
-#else
-        float4 c = trace_pixel_dev<BVH, false, TWOCHILD>(S, cam, P, h, v, -1, id, C, R);
-#endif
         size_t idx = (size_t)(P.compact ? r : h) * cam.width + v; // RayTracerUnity.cs:442
         rgba[idx] = c;
         if (hit_id) hit_id[idx] = id;
     }
+#else
+    f3 raw = mk3(0.f, 0.f, 0.f);
+    const float2* off = nullptr;
+    if (inside) {
+        raw = camera_raw_dir(cam, h, v);
+        unsigned pixel = (unsigned)(h * cam.width + v);
+        unsigned set = pixel_set_dev(P.seed, pixel, (unsigned)P.n_sets);
+        off = P.offsets ? P.offsets + (size_t)set * P.spp : nullptr;
+    }
+    f3 sum = mk3(0.f, 0.f, 0.f);
+    int id = -1;
+    for (int base = 0; base < P.spp; base += n_sl) {   // wave-uniform trip count
+        const int i = base + si;
+        f3 c = mk3(0.f, 0.f, 0.f);
+        if (inside && i < P.spp) {
+            int fp;
+            c = trace_sample_dev<BVH, false, TWOCHILD>(S, cam, P, raw, off, i, fp, C, R);
+            if (i == 0) id = fp;
+        }
+        if (shift == 0) {
+            sum = sum + c;
+        } else {
+            // ordered sum: every lane of the pixel adds samples base, base+1, ... in turn
+            const int first_lane = lane & ~(n_sl - 1);
+            const int n_here = min(n_sl, P.spp - base);
+            for (int k = 0; k < n_here; ++k) {
+                f3 q = mk3(__shfl(c.x, first_lane + k, 64), __shfl(c.y, first_lane + k, 64),
+                           __shfl(c.z, first_lane + k, 64));
+                sum = sum + q;
+            }
+        }
+    }
+    if (inside && si == 0) {
+        f3 fin = sum / (float)P.spp;
+        size_t idx = (size_t)(P.compact ? r : h) * cam.width + v; // RayTracerUnity.cs:442
+        rgba[idx] = process_color(fin);
+        if (hit_id) hit_id[idx] = id;
+    }
+#endif
     flush_counters(C, ctr, blockIdx.x);
 }
 
@@ -152,7 +199,13 @@ static inline int div_up(int a, int b) { return (a + b - 1) / b; }
 hipError_t vrt_launch_mega(const DevScene& S, const DevCam& cam, const DevParams& P, bool bvh, bool twochild,
                            float4* rgba, int* hit_id, unsigned long long* ctr, hipStream_t stream)
 {
-    int blocks_x = div_up(cam.width, VRT_MEGA_THREADS / 8), blocks_y = div_up(P.local_rows, 8);
+#if VRT_USE_SM
+    const int shift = 0;
+#else
+    const int shift = P.sample_shift;
+#endif
+    const int pshift = 6 - shift, pw_shift = (pshift + 1) >> 1;
+    int blocks_x = div_up(cam.width, 1 << pw_shift), blocks_y = div_up(P.local_rows, 1 << (pshift - pw_shift));
     int n_blocks = blocks_x * blocks_y;
     if (n_blocks <= 0) return hipSuccess;
     dim3 grid(n_blocks), block(VRT_MEGA_THREADS);

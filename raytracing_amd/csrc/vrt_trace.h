@@ -63,6 +63,56 @@ __device__ __forceinline__ bool hit_sphere(float4 s, f3 o, f3 d, float maxd, flo
     return t >= 0.f && t <= maxd;
 }
 
+// The same test for a ray leaving the camera origin: oc = origin - centre and
+// cc = oc.oc - r*r do not depend on the pixel and come precomputed (same float operations,
+// same order, done once on the host).
+__device__ __forceinline__ bool hit_sphere_pre(float4 pre, f3 d, float maxd, float& t)
+{
+    float b = dot3(xyz(pre), d);
+    float cc = pre.w;
+    float disc = b * b - cc;
+    if (!(cc > 0.f && b < 0.f && disc >= 0.f)) return false;
+    t = -b - sqrtf(disc);
+    return t >= 0.f && t <= maxd;
+}
+
+// Box whose axes are signed world axes: local axis k_j = +-e_j.  The local quantities of the
+// general test are then exact sign flips of world ones (p.A = +-p_j, d.A = +-d_j,
+// 1/(d.A) = +-(1/d_j)), so the slabs can be evaluated on world coordinates with one reciprocal
+// per ray component, bit for bit like box_slabs: a sign flip swaps t1 and t2 together with the
+// sign of the direction, which leaves the near/far values unchanged.  Only the face code needs
+// the local view: aux = k_j | (entered through the +axis face ? 4 : 0), and among equal
+// near values the lowest local axis wins as in box_slabs' ascending loop.
+// p = origin - centre, inv = 1/d per component, fl = k_0 | k_1<<2 | k_2<<4 | flip_j<<(8+j).
+__device__ __forceinline__ bool hit_aab(f3 p, f3 d, f3 inv, float h0, float h1, float h2, int fl, float maxd,
+                                        float& t, int& aux)
+{
+    bool inside = (fabsf(p.x) <= h0) && (fabsf(p.y) <= h1) && (fabsf(p.z) <= h2);
+    if (inside) return false;
+    float tn = -INFINITY, tf = INFINITY;
+    int ax = -1, kb = -1;
+#define VRT_WSLAB(J, PJ, DJ, INV, H)                                                   \
+    if (DJ == 0.f) { if (fabsf(PJ) > H) return false; }                                \
+    else {                                                                             \
+        const int kj = (fl >> (2 * J)) & 3;                                            \
+        const bool flip = ((fl >> (8 + J)) & 1) != 0;                                  \
+        float t1 = (-H - PJ) * INV, t2 = (H - PJ) * INV;                               \
+        bool pos = DJ > 0.f;                                                           \
+        float nr = pos ? t1 : t2, fr = pos ? t2 : t1;                                  \
+        if (nr > tn || (nr == tn && kj < kb)) { tn = nr; kb = kj; ax = kj | ((pos == flip) ? 4 : 0); } \
+        if (fr < tf) tf = fr;                                                          \
+    }
+    VRT_WSLAB(0, p.x, d.x, inv.x, h0)
+    VRT_WSLAB(1, p.y, d.y, inv.y, h1)
+    VRT_WSLAB(2, p.z, d.z, inv.z, h2)
+#undef VRT_WSLAB
+    if (ax < 0) return false;
+    if (!(tn <= tf)) return false;
+    if (!(tn >= 0.f && tn <= maxd)) return false;
+    t = tn; aux = ax;
+    return true;
+}
+
 // Slab core of the box test on box-local coordinates: lo = origin, ld = direction, inv = 1/ld.
 // aux = axis | (entered through the +axis face ? 4 : 0)
 __device__ __forceinline__ bool box_slabs(float lo0, float lo1, float lo2, float ld0, float ld1, float ld2,
@@ -146,32 +196,60 @@ __device__ __forceinline__ void test_prim(const DevScene& S, int id, f3 o, f3 d,
 // testing i, and a division-free path for axis-aligned boxes, were both measured slower on
 // MI355X and are not used.)
 // ANY: stop at the first primitive hit with t < tlim (and t <= maxd).
+// CAM: the ray starts at the camera origin and S.cam_pre holds the per-primitive terms that
+// depend only on the origin.
+#ifndef VRT_AAB_CULL
+#define VRT_AAB_CULL 0
+#endif
+template <bool CAM>
 __device__ __forceinline__ Hit intersect_brute(const DevScene& S, f3 o, f3 d, float maxd, float tlim, int skip, bool ANY)
 {
     Hit best; best.t = INFINITY; best.prim = -1; best.aux = 0;
     if (is_zero3(d)) return best;
     for (int i = 0; i < S.n_sph; ++i) {
         float t;
-        if (i != skip && hit_sphere(S.sph[i], o, d, maxd, t) && t < best.t && t < tlim) {
+        bool h = CAM ? hit_sphere_pre(S.cam_pre[i], d, maxd, t) : hit_sphere(S.sph[i], o, d, maxd, t);
+        if (i != skip && h && t < best.t && t < tlim) {
             best.t = t; best.prim = i;
             if (ANY) return best;
         }
     }
-    for (int i = 0; i < S.n_box; ++i) {
-        float t; int aux;
-        const float4* b = S.box + 4 * i;
-        // Conservative cull: b[3].w = squared circumradius of the box.  A ray that clears the
-        // circumsphere (with 32 ulp of |oc|^2 slack for rounding) cannot touch the box; when
-        // no lane of the wave can, the slab test with its three divisions is skipped.
-        float4 bc = b[0];
-        f3 oc = o - xyz(bc);
-        float oo = dot3(oc, oc), bb = dot3(oc, d);
-        float cs = oo - b[3].w, slack = 4e-6f * oo;
-        bool may = !((bb * bb - cs + slack < 0.f) || (cs > slack && bb > 0.f));
-        if (!__any(may)) continue;
-        if (i + S.n_sph != skip && hit_box(b[0], b[1], b[2], b[3], o, d, maxd, t, aux) && t < best.t && t < tlim) {
-            best.t = t; best.prim = i + S.n_sph; best.aux = aux;
-            if (ANY) return best;
+    if (S.all_aab) {
+        // every box is aligned with the world axes: one reciprocal per ray component serves all
+        const f3 inv = mk3(1.f / d.x, 1.f / d.y, 1.f / d.z);
+        for (int i = 0; i < S.n_box; ++i) {
+            float t; int aux;
+            const float4 a0 = S.aab[2 * i], a1 = S.aab[2 * i + 1];
+            const f3 p = CAM ? xyz(S.cam_pre[S.n_sph + i]) : o - xyz(a0);
+#if VRT_AAB_CULL
+            float oo = dot3(p, p), bb = dot3(p, d);
+            float cs = oo - a1.w, slack = 4e-6f * oo;
+            bool may = !((bb * bb - cs + slack < 0.f) || (cs > slack && bb > 0.f));
+            if (!__any(may)) continue;
+#endif
+            if (i + S.n_sph != skip && hit_aab(p, d, inv, a1.x, a1.y, a1.z, __float_as_int(a0.w), maxd, t, aux) &&
+                t < best.t && t < tlim) {
+                best.t = t; best.prim = i + S.n_sph; best.aux = aux;
+                if (ANY) return best;
+            }
+        }
+    } else {
+        for (int i = 0; i < S.n_box; ++i) {
+            float t; int aux;
+            const float4* b = S.box + 4 * i;
+            // Conservative cull: b[3].w = squared circumradius of the box.  A ray that clears the
+            // circumsphere (with 32 ulp of |oc|^2 slack for rounding) cannot touch the box; when
+            // no lane of the wave can, the slab test with its three divisions is skipped.
+            float4 bc = b[0];
+            f3 oc = o - xyz(bc);
+            float oo = dot3(oc, oc), bb = dot3(oc, d);
+            float cs = oo - b[3].w, slack = 4e-6f * oo;
+            bool may = !((bb * bb - cs + slack < 0.f) || (cs > slack && bb > 0.f));
+            if (!__any(may)) continue;
+            if (i + S.n_sph != skip && hit_box(b[0], b[1], b[2], b[3], o, d, maxd, t, aux) && t < best.t && t < tlim) {
+                best.t = t; best.prim = i + S.n_sph; best.aux = aux;
+                if (ANY) return best;
+            }
         }
     }
     for (int i = 0; i < S.n_tri; ++i) {
@@ -352,11 +430,11 @@ __device__ __forceinline__ Hit intersect_bvh4(const DevScene& S, f3 o, f3 d, flo
 }
 
 // Closest hit (ANY = false) or "some hit with t < tlim" (ANY = true) within maxd.
-template <bool BVH, bool ANY>
+template <bool BVH, bool ANY, bool CAM = false>
 __device__ __forceinline__ Hit intersect(const DevScene& S, f3 o, f3 d, float maxd, int skip, float tlim = INFINITY)
 {
     if (BVH) return VRT_BVH4 ? intersect_bvh4(S, o, d, maxd, tlim, skip, ANY) : intersect_bvh(S, o, d, maxd, tlim, skip, ANY);
-    return intersect_brute(S, o, d, maxd, tlim, skip, ANY);
+    return intersect_brute<CAM>(S, o, d, maxd, tlim, skip, ANY);
 }
 
 // The same with the any-hit choice made per lane at run time.
@@ -364,7 +442,7 @@ template <bool BVH>
 __device__ __forceinline__ Hit intersect_rt(const DevScene& S, f3 o, f3 d, float maxd, int skip, float tlim, bool any)
 {
     if (BVH) return VRT_BVH4 ? intersect_bvh4(S, o, d, maxd, tlim, skip, any) : intersect_bvh(S, o, d, maxd, tlim, skip, any);
-    return intersect_brute(S, o, d, maxd, tlim, skip, any);
+    return intersect_brute<false>(S, o, d, maxd, tlim, skip, any);
 }
 
 // hit.point = origin + direction * distance; hit.normal per collider type.
@@ -654,6 +732,35 @@ __device__ __forceinline__ f3 trace_path(const DevScene& S, const DevParams& P, 
     return L;
 }
 
+// RayTracerUnity.cs:578-587: anti-aliasing sample i of pixel (h, v): its radiance, or zero when
+// the primary any-hit pre-check fails (sky with VRT_FIX_PRIMARY_SKY).  `off` = the pixel's row
+// of the offset table or null.
+template <bool BVH, bool RECORD, bool TWOCHILD>
+__device__ __forceinline__ f3 trace_sample_dev(const DevScene& S, const DevCam& cam, const DevParams& P, f3 raw,
+                                               const float2* off, int i, int& first_prim, Counters& C, Recorder& R)
+{
+    f3 O = mk3(cam.ox, cam.oy, cam.oz);
+    float ox = 0.f, oy = 0.f;
+    if (off) { float2 q = off[i]; ox = q.x; oy = q.y; }
+    f3 d = normalize3(mk3(raw.x + ox, raw.y + oy, raw.z));
+    R.sample = i;
+    Hit first; first.prim = -1; first.t = INFINITY; first.aux = 0;
+    if (!is_zero3(d)) {
+        // one closest-hit query answers both the any-hit pre-check (RayTracerUnity.cs:582)
+        // and the primary TraceRay (:584); they are counted as the two queries they replace
+        C.precheck++;
+        first = intersect<BVH, false, true>(S, O, d, P.range, -1);
+    }
+    first_prim = first.prim;
+    if (first.prim >= 0) {
+        C.primary++;
+        record_seg<RECORD>(R, O, d, first, VRT_RAY_PRIMARY, 0, P.range);
+        return trace_path<BVH, RECORD, TWOCHILD>(S, P, O, d, first, C, R);
+    }
+    if (P.flags & VRT_FIX_PRIMARY_SKY) return sky_color(d);
+    return mk3(0.f, 0.f, 0.f);
+}
+
 // RayTracerUnity.cs:565-597: all samples of one pixel, averaged and tone-mapped.
 // sample_sel < 0: every sample; otherwise just that one (single-step mode).
 template <bool BVH, bool RECORD, bool TWOCHILD>
@@ -661,7 +768,6 @@ __device__ __forceinline__ float4 trace_pixel_dev(const DevScene& S, const DevCa
                                                   int h, int v, int sample_sel, int& hit_id,
                                                   Counters& C, Recorder& R)
 {
-    f3 O = mk3(cam.ox, cam.oy, cam.oz);
     f3 raw = camera_raw_dir(cam, h, v);
     unsigned pixel = (unsigned)(h * cam.width + v);
     unsigned set = pixel_set_dev(P.seed, pixel, (unsigned)P.n_sets);
@@ -670,25 +776,10 @@ __device__ __forceinline__ float4 trace_pixel_dev(const DevScene& S, const DevCa
     hit_id = -1;
     int i0 = sample_sel < 0 ? 0 : sample_sel, i1 = sample_sel < 0 ? P.spp : sample_sel + 1;
     for (int i = i0; i < i1; ++i) {
-        float ox = 0.f, oy = 0.f;
-        if (off) { float2 q = off[i]; ox = q.x; oy = q.y; }
-        f3 d = normalize3(mk3(raw.x + ox, raw.y + oy, raw.z));
-        R.sample = i;
-        Hit first; first.prim = -1; first.t = INFINITY; first.aux = 0;
-        if (!is_zero3(d)) {
-            // one closest-hit query answers both the any-hit pre-check (RayTracerUnity.cs:582)
-            // and the primary TraceRay (:584); they are counted as the two queries they replace
-            C.precheck++;
-            first = intersect<BVH, false>(S, O, d, P.range, -1);
-        }
-        if (i == 0) hit_id = first.prim;
-        if (first.prim >= 0) {
-            C.primary++;
-            record_seg<RECORD>(R, O, d, first, VRT_RAY_PRIMARY, 0, P.range);
-            sum = sum + trace_path<BVH, RECORD, TWOCHILD>(S, P, O, d, first, C, R);
-        } else if (P.flags & VRT_FIX_PRIMARY_SKY) {
-            sum = sum + sky_color(d);
-        }
+        int fp;
+        f3 c = trace_sample_dev<BVH, RECORD, TWOCHILD>(S, cam, P, raw, off, i, fp, C, R);
+        if (i == 0) hit_id = fp;
+        sum = sum + c;
     }
     f3 fin = sum / (float)(i1 - i0);
     return process_color(fin);

@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void k_wf_primary(DevScene S, DevCam cam, DevP
         d = normalize3(mk3(raw.x + ox, raw.y + oy, raw.z));
         if (!is_zero3(d)) {
             C.precheck++;
-            first = intersect<BVH, false>(S, O, d, P.range, -1);
+            first = intersect<BVH, false, true>(S, O, d, P.range, -1);
         }
         if (first.prim >= 0) C.primary++;
         else if (P.flags & VRT_FIX_PRIMARY_SKY) L = sky_color(d);
