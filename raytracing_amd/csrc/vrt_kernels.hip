@@ -55,8 +55,11 @@ __device__ __forceinline__ void flush_counters(const Counters& C, unsigned long 
 // P.xcd_remap (off by default, see vrt_api.hip) renumbers blocks so that the 8 blocks dealt
 // round-robin to the 8 XCDs come from 8 separate bands of the image.
 #define VRT_MEGA_THREADS 64
+#ifndef VRT_BVH_WAVES
+#define VRT_BVH_WAVES 4
+#endif
 template <bool BVH, bool TWOCHILD>
-__global__ __launch_bounds__(VRT_MEGA_THREADS, BVH ? 5 : 4) void k_mega(DevScene S, DevCam cam, DevParams P, float4* __restrict__ rgba,
+__global__ __launch_bounds__(VRT_MEGA_THREADS, BVH ? VRT_BVH_WAVES : 4) void k_mega(DevScene S, DevCam cam, DevParams P, float4* __restrict__ rgba,
                                               int* __restrict__ hit_id, unsigned long long* ctr,
                                               int blocks_x, int n_blocks)
 {

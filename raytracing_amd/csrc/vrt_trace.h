@@ -14,6 +14,7 @@
 #endif
 
 
+typedef float v2f __attribute__((ext_vector_type(2))); // maps to v_pk_add_f32 / v_pk_mul_f32
 struct f3 { float x, y, z; };
 __device__ __forceinline__ f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
 __device__ __forceinline__ f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
@@ -340,7 +341,9 @@ __device__ __forceinline__ Hit intersect_bvh(const DevScene& S, f3 o, f3 d, floa
 #ifndef VRT_BVH4
 #define VRT_BVH4 1
 #endif
+#ifndef VRT_LDS_STACK4
 #define VRT_LDS_STACK4 12
+#endif
 
 // Orders two (tnear, code) candidates, nearer first.
 __device__ __forceinline__ void order2(float& ta, int& ca, float& tb, int& cb)
@@ -377,10 +380,28 @@ __device__ __forceinline__ Hit intersect_bvh4(const DevScene& S, f3 o, f3 d, flo
             const float lim = best.prim >= 0 ? best.t : lim0;
             int c0 = __float_as_int(cc.x), c1 = __float_as_int(cc.y), c2 = __float_as_int(cc.z), c3 = __float_as_int(cc.w);
             float t0, t1, t2, t3;
-            bool h0 = slab_test(mk3(lx.x, ly.x, lz.x), mk3(hx.x, hy.x, hz.x), o, inv, lim, t0);
-            bool h1 = slab_test(mk3(lx.y, ly.y, lz.y), mk3(hx.y, hy.y, hz.y), o, inv, lim, t1);
-            bool h2 = slab_test(mk3(lx.z, ly.z, lz.z), mk3(hx.z, hy.z, hz.z), o, inv, lim, t2);
-            bool h3 = slab_test(mk3(lx.w, ly.w, lz.w), mk3(hx.w, hy.w, hz.w), o, inv, lim, t3);
+            bool h0, h1, h2, h3;
+            {   // the four slab tests of slab_test(), children (0,1) and (2,3) as packed pairs
+                const v2f ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
+                const v2f ix = {inv.x, inv.x}, iy = {inv.y, inv.y}, iz = {inv.z, inv.z};
+                const v2f ax01 = (v2f{lx.x, lx.y} - ox) * ix, ax23 = (v2f{lx.z, lx.w} - ox) * ix;
+                const v2f bx01 = (v2f{hx.x, hx.y} - ox) * ix, bx23 = (v2f{hx.z, hx.w} - ox) * ix;
+                const v2f ay01 = (v2f{ly.x, ly.y} - oy) * iy, ay23 = (v2f{ly.z, ly.w} - oy) * iy;
+                const v2f by01 = (v2f{hy.x, hy.y} - oy) * iy, by23 = (v2f{hy.z, hy.w} - oy) * iy;
+                const v2f az01 = (v2f{lz.x, lz.y} - oz) * iz, az23 = (v2f{lz.z, lz.w} - oz) * iz;
+                const v2f bz01 = (v2f{hz.x, hz.y} - oz) * iz, bz23 = (v2f{hz.z, hz.w} - oz) * iz;
+#define VRT_SLAB4(T, H, AX, BX, AY, BY, AZ, BZ)                                                       \
+                {                                                                                     \
+                    float n_ = fmaxf(fmaxf(fminf(AX, BX), fminf(AY, BY)), fmaxf(fminf(AZ, BZ), 0.f)); \
+                    float f_ = fminf(fminf(fmaxf(AX, BX), fmaxf(AY, BY)), fminf(fmaxf(AZ, BZ), lim)); \
+                    T = n_; H = n_ <= f_ * 1.0000004f;                                                \
+                }
+                VRT_SLAB4(t0, h0, ax01.x, bx01.x, ay01.x, by01.x, az01.x, bz01.x)
+                VRT_SLAB4(t1, h1, ax01.y, bx01.y, ay01.y, by01.y, az01.y, bz01.y)
+                VRT_SLAB4(t2, h2, ax23.x, bx23.x, ay23.x, by23.x, az23.x, bz23.x)
+                VRT_SLAB4(t3, h3, ax23.y, bx23.y, ay23.y, by23.y, az23.y, bz23.y)
+#undef VRT_SLAB4
+            }
             t0 = (h0 && c0 != VRT_BVH4_EMPTY) ? t0 : INFINITY;
             t1 = (h1 && c1 != VRT_BVH4_EMPTY) ? t1 : INFINITY;
             t2 = (h2 && c2 != VRT_BVH4_EMPTY) ? t2 : INFINITY;
