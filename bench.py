@@ -368,6 +368,9 @@ def main():
             "ms_per_frame_kernel": kernel_ms,
             "roofline": roof,
         }
+        if st.nodes_visited:  # only a library built with -DVRT_COUNT_NODES=1 counts these
+            out["traversal"] = {"nodes_per_ray": st.nodes_visited / max(my_queries, 1),
+                                "prims_per_ray": st.prims_tested / max(my_queries, 1)}
         if frames_match is not None:
             out["gathered_frame_equals_single_gpu_frame"] = frames_match
         if s8k is not None:

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define VRT_ABI_VERSION 1
+#define VRT_ABI_VERSION 2
 
 typedef struct vrt_ctx vrt_ctx;
 
@@ -207,6 +207,8 @@ typedef struct vrt_stats {
     float bvh_build_ms;             /* device time of the last LBVH build (vrt_set_scene) */
     uint32_t bvh_nodes;
     int32_t mode_used;              /* VRT_MODE_* actually run */
+    uint64_t nodes_visited;         /* LBVH nodes entered and primitives tested by the call, per lane; */
+    uint64_t prims_tested;          /* counted only by a library built with -DVRT_COUNT_NODES=1, else 0 */
 } vrt_stats;
 
 /* Lifetime.  Replaces RayTracerUnity.Start (RayTracerUnity.cs:266-307), which builds the

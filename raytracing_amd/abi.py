@@ -5,7 +5,7 @@ test-side oracle binding can share the data formats.
 """
 import ctypes as C
 
-VRT_ABI_VERSION = 1
+VRT_ABI_VERSION = 2
 
 VRT_OK = 0
 VRT_ERR_INVALID = -1
@@ -95,7 +95,8 @@ class vrt_params(C.Structure):
 class vrt_stats(C.Structure):
     _fields_ = [("rays", C.c_uint64 * VRT_RAY_CLASSES), ("pixels", C.c_uint64),
                 ("gpu_ms", C.c_float), ("bvh_build_ms", C.c_float),
-                ("bvh_nodes", C.c_uint32), ("mode_used", C.c_int32)]
+                ("bvh_nodes", C.c_uint32), ("mode_used", C.c_int32),
+                ("nodes_visited", C.c_uint64), ("prims_tested", C.c_uint64)]
 
 
 # Every symbol include/vrt.h declares; tests check the built library exports all of them.

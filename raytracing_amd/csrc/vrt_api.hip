@@ -283,6 +283,7 @@ extern "C" int vrt_set_scene(vrt_ctx* c, const vrt_scene_desc* d)
     HIPCHK(c, upload(&c->d_lights, lights));
     S.lights = c->d_lights;
     S.sh = d->shading;
+    S.dbg = c->d_ctr;
 
     c->use_bvh = n_prims > kBruteMaxPrims;
     c->bvh_ms = 0.f; c->bvh_depth = 0;
@@ -447,6 +448,10 @@ static int read_stats(vrt_ctx* c, vrt_stats* s)
     memset(s, 0, sizeof *s);
     for (int i = 0; i < VRT_CTR_SLOTS; ++i)
         for (int k = 0; k < VRT_RAY_CLASSES; ++k) s->rays[k] += h[i * VRT_CTR_STRIDE + k];
+    for (int i = 0; i < VRT_CTR_SLOTS; ++i) {
+        s->nodes_visited += h[i * VRT_CTR_STRIDE + 6];
+        s->prims_tested += h[i * VRT_CTR_STRIDE + 7];
+    }
     s->pixels = c->last_pixels;
     s->bvh_build_ms = c->bvh_ms;
     s->bvh_nodes = c->use_bvh ? (uint32_t)(c->scene.n_prims - 1) : 0;

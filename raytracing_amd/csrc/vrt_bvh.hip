@@ -246,7 +246,9 @@ __global__ __launch_bounds__(256) void k_collapse4(int n_inner, const float4* __
         }
     }
     for (; m < 4; ++m) {
-        for (int k = 0; k < 3; ++k) { lo[m][k] = INFINITY; hi[m][k] = -INFINITY; }
+        // lo = hi = +inf: (inf - o) * inv is +inf or -inf on both planes, which fails the slab
+        // test for every ray, so the traversal needs no separate check for unused slots
+        for (int k = 0; k < 3; ++k) { lo[m][k] = INFINITY; hi[m][k] = INFINITY; }
         code[m] = VRT_BVH4_EMPTY;
     }
     float4* w = wide + 8 * (size_t)i;

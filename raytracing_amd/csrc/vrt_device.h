@@ -44,6 +44,7 @@ struct DevScene {
     const float4* cam_pre; // per sphere (o-c, |o-c|^2 - r^2), per box (o-c, 0) for o = camera origin
     int n_lights;
     const DevLight* lights; // n_lights entries in device memory
+    unsigned long long* dbg; // the context's counter block (slots 6, 7: nodes entered, primitives tested)
     vrt_shading sh;
 };
 

@@ -344,6 +344,9 @@ __device__ __forceinline__ Hit intersect_bvh(const DevScene& S, f3 o, f3 d, floa
 #ifndef VRT_LDS_STACK4
 #define VRT_LDS_STACK4 12
 #endif
+#ifndef VRT_LEAF_BATCH
+#define VRT_LEAF_BATCH 0
+#endif
 
 // Orders two (tnear, code) candidates, nearer first.
 __device__ __forceinline__ void order2(float& ta, int& ca, float& tb, int& cb)
@@ -351,6 +354,19 @@ __device__ __forceinline__ void order2(float& ta, int& ca, float& tb, int& cb)
     bool s = tb < ta;
     float t = s ? tb : ta; tb = s ? ta : tb; ta = t;
     int c = s ? cb : ca; cb = s ? ca : cb; ca = c;
+}
+
+// Debug build only (-DVRT_COUNT_NODES=1): adds the number of active lanes to counter word `k`.
+#ifndef VRT_COUNT_NODES
+#define VRT_COUNT_NODES 0
+#endif
+__device__ __forceinline__ void count_lanes(const DevScene& S, int k)
+{
+#if VRT_COUNT_NODES
+    unsigned long long m = __ballot(1);
+    if ((int)(threadIdx.x & 63) == __ffsll((long long)m) - 1)
+        atomicAdd(&S.dbg[(blockIdx.x % VRT_CTR_SLOTS) * VRT_CTR_STRIDE + k], (unsigned long long)__popcll(m));
+#endif
 }
 
 // Stack-based traversal of the 4-wide tree.  One step loads one 128-byte node and tests its
@@ -372,9 +388,18 @@ __device__ __forceinline__ Hit intersect_bvh4(const DevScene& S, f3 o, f3 d, flo
     int node = 0;
     bool done = false;
     // every node is entered at most once; the bound only guards against a corrupt tree
-    for (int guard = 2 * S.n_prims + 8; guard > 0 && !done; --guard) {
+    for (int guard = (VRT_LEAF_BATCH ? 64 : 1) * (2 * S.n_prims + 8); guard > 0 && !done; --guard) {
         bool pop = true;
+#if VRT_LEAF_BATCH
+        // A lane that holds a leaf waits until VRT_LEAF_BATCH lanes of the wave do, or until no
+        // lane has an inner node left: the primitive test then runs for many lanes at once
+        // instead of once per step for a few.
+        const bool leaf_now = __popcll(__ballot(node < 0)) >= VRT_LEAF_BATCH || !__any(node >= 0);
+#else
+        const bool leaf_now = true;
+#endif
         if (node >= 0) {
+            count_lanes(S, 6);
             const float4* n = S.bvh4 + 8 * (size_t)node;
             const float4 lx = n[0], ly = n[1], lz = n[2], hx = n[3], hy = n[4], hz = n[5], cc = n[6];
             const float lim = best.prim >= 0 ? best.t : lim0;
@@ -402,10 +427,11 @@ __device__ __forceinline__ Hit intersect_bvh4(const DevScene& S, f3 o, f3 d, flo
                 VRT_SLAB4(t3, h3, ax23.y, bx23.y, ay23.y, by23.y, az23.y, bz23.y)
 #undef VRT_SLAB4
             }
-            t0 = (h0 && c0 != VRT_BVH4_EMPTY) ? t0 : INFINITY;
-            t1 = (h1 && c1 != VRT_BVH4_EMPTY) ? t1 : INFINITY;
-            t2 = (h2 && c2 != VRT_BVH4_EMPTY) ? t2 : INFINITY;
-            t3 = (h3 && c3 != VRT_BVH4_EMPTY) ? t3 : INFINITY;
+            // unused slots hold boxes at +inf, which no ray passes
+            t0 = h0 ? t0 : INFINITY;
+            t1 = h1 ? t1 : INFINITY;
+            t2 = h2 ? t2 : INFINITY;
+            t3 = h3 ? t3 : INFINITY;
             if (!ANY) {
                 order2(t0, c0, t1, c1); order2(t2, c2, t3, c3);
                 order2(t0, c0, t2, c2); order2(t1, c1, t3, c3);
@@ -431,10 +457,13 @@ __device__ __forceinline__ Hit intersect_bvh4(const DevScene& S, f3 o, f3 d, flo
                 VRT_PUSH4(t1, c1)
 #undef VRT_PUSH4
             }
-        } else {
+        } else if (leaf_now) {
             int id = ~node;
+            count_lanes(S, 7);
             if (id != skip) test_prim(S, id, o, d, maxd, best);
             if (ANY && best.prim >= 0) { if (best.t < tlim) return best; best.prim = -1; best.t = INFINITY; }
+        } else {
+            pop = false;
         }
         if (pop) {
             const float lim = best.prim >= 0 ? best.t : lim0;
