@@ -1,0 +1,111 @@
+"""Kernel organisation must not change results: the pixel x sample lane split of the megakernel,
+the world-axis box test and the general oriented-box test all have to agree with the oracle, and
+the lane split has to be invisible bit for bit."""
+import os
+
+import numpy as np
+import pytest
+
+import raytracing_amd as ra
+from raytracing_amd import abi, host
+
+pytestmark = pytest.mark.gpu
+TOL = 1.0 / 255.0
+
+
+def _render_with_shift(ctx, prm, shift):
+    old = os.environ.get("VRT_SAMPLE_SHIFT")
+    try:
+        if shift is None:
+            os.environ.pop("VRT_SAMPLE_SHIFT", None)
+        else:
+            os.environ["VRT_SAMPLE_SHIFT"] = str(shift)
+        rgba, hit, st = ctx.render(prm)
+        return rgba.copy(), hit.copy(), np.array(st.rays[:], np.uint64)
+    finally:
+        if old is None:
+            os.environ.pop("VRT_SAMPLE_SHIFT", None)
+        else:
+            os.environ["VRT_SAMPLE_SHIFT"] = old
+
+
+@pytest.mark.parametrize("spp", [1, 3, 4, 16, 50])
+@pytest.mark.parametrize("bvh", [False, True])
+def test_sample_lane_split_is_bitwise_invisible(vrt_ctx, spp, bvh):
+    """Every split of the 64 lanes into pixels x samples sums the samples in the same order, so
+    frames, hit ids and ray counts are identical to one lane per pixel (odd frame sizes and
+    sample counts that do not fill the lanes included)."""
+    scene = ra.random_spheres_scene(300) if bvh else ra.teaching_scene()
+    cam = ra.random_spheres_camera(75, 53) if bvh else ra.teaching_camera(75, 53)
+    offs = host.sampler_table(abi.VRT_SAMPLER_JITTERED if spp in (1, 4, 16) else abi.VRT_SAMPLER_RANDOM,
+                              spp, 5, 0.02, 0.02, seed=11)
+    prm = ra.Params(spp=spp, offsets=offs, seed=5, max_depth=4, rng=200.0)
+    vrt_ctx.set_scene(scene)
+    vrt_ctx.set_camera(cam)
+    ref = _render_with_shift(vrt_ctx, prm, 0)
+    for shift in (None, 1, 2, 4, 6):
+        got = _render_with_shift(vrt_ctx, prm, shift)
+        assert np.array_equal(got[0], ref[0], equal_nan=True), f"rgba differs at shift {shift}"
+        assert np.array_equal(got[1], ref[1]) and np.array_equal(got[2], ref[2])
+
+
+def _check(ctx, oracle_mod, scene, cam, prm):
+    ctx.set_scene(scene)
+    ctx.set_camera(cam)
+    rgba, hit, st = ctx.render(prm)
+    o_rgba, o_hit, o_rays = oracle_mod.render(scene, cam, prm.c, n_threads=8)
+    assert np.array_equal(hit, o_hit)
+    assert np.array_equal(np.array(st.rays[:], np.uint64), o_rays)
+    both_nan = np.isnan(rgba) & np.isnan(o_rgba)
+    err = np.abs(np.where(both_nan, 0, rgba) - np.where(both_nan, 0, o_rgba))
+    assert not np.isnan(err).any() and err.max() <= TOL
+    return hit
+
+
+def _box_scene(axes_list):
+    s = ra.Scene()
+    red = s.add_material("Red", abi.VRT_MAT_SOLID, (1, 0.2, 0.2))
+    metal = s.add_material("Metal", abi.VRT_MAT_METAL, (0.9, 0.9, 0.9))
+    wood = s.add_material("Wood", abi.VRT_MAT_SOLID, (0.8, 0.6, 0.3))
+    s.add_sphere((0.3, 0.8, 0.2), 0.8, metal)
+    s.add_box((0, -0.5, 0), (6, 0.5, 6), wood)
+    for k, axes in enumerate(axes_list):
+        s.add_box((-2.0 + 1.7 * k, 0.6, 1.0 - 0.4 * k), (0.5, 0.6, 0.3), red if k % 2 else metal, axes=axes)
+    s.add_light(abi.VRT_LIGHT_POINT, (3, 6, -4), ls=1.0, cast_shadows=True)
+    s.add_light(abi.VRT_LIGHT_DIRECTIONAL, (0.3, 0.8, -0.5), ls=0.5, cast_shadows=False)
+    return s
+
+
+def test_signed_permuted_box_axes(vrt_ctx, oracle_mod):
+    """Boxes whose axes are signed permutations of the world axes take the world-axis slab test;
+    face ids, normals and tie-breaks must be those of the oracle's oriented-box test."""
+    axes = [((0, 0, -1), (0, 1, 0), (1, 0, 0)), ((0, -1, 0), (-1, 0, 0), (0, 0, 1)),
+            ((0, 1, 0), (0, 0, 1), (1, 0, 0)), ((-1, 0, 0), (0, -1, 0), (0, 0, -1))]
+    cam = ra.make_camera((0, 2.5, -7), (-3, -0.5, -3), (6, 0, 0), (0, 4.5, 0), 160, 120)
+    hit = _check(vrt_ctx, oracle_mod, _box_scene(axes), cam, ra.Params(spp=1, max_depth=6))
+    assert len(np.unique(hit)) >= 6
+
+
+def test_rotated_boxes_use_the_oriented_test(vrt_ctx, oracle_mod):
+    c, s = np.cos(0.5), np.sin(0.5)
+    rot = ((c, 0, -s), (0, 1, 0), (s, 0, c))
+    axes = [rot, None, ((0, 0, -1), (0, 1, 0), (1, 0, 0))]
+    cam = ra.make_camera((0, 2.5, -7), (-3, -0.5, -3), (6, 0, 0), (0, 4.5, 0), 160, 120)
+    _check(vrt_ctx, oracle_mod, _box_scene(axes), cam, ra.Params(spp=1, max_depth=6))
+
+
+def test_rays_along_box_edges_and_axes(vrt_ctx, oracle_mod):
+    """A camera aligned with the world axes looks exactly along box faces and at box edges:
+    zero direction components and equal slab distances exercise the tie rules."""
+    s = ra.Scene()
+    m = s.add_material("Blue", abi.VRT_MAT_SOLID, (0.1, 0.3, 1.0))
+    g = s.add_material("Metal", abi.VRT_MAT_METAL, (0.9, 0.9, 0.9))
+    s.add_box((0, 0, 0), (1, 1, 1), m, axes=((0, 1, 0), (1, 0, 0), (0, 0, 1)))
+    s.add_box((2, 0, 0), (1, 1, 1), g)
+    s.add_box((0, -2, 0), (4, 1, 4), m, axes=((0, 0, 1), (0, -1, 0), (1, 0, 0)))
+    s.add_light(abi.VRT_LIGHT_POINT, (0, 5, -5), ls=1.0, cast_shadows=True)
+    # pixel corners fall exactly on x = -1, 0, 1 ... and y = -1, 0, 1 at the z = -1 face
+    cam = ra.make_camera((0, 0, -5), (-4, -4, -1), (8, 0, 0), (0, 8, 0), 64, 64)
+    _check(vrt_ctx, oracle_mod, s, cam, ra.Params(spp=1, max_depth=3))
+    cam2 = ra.make_camera((1, 1, -5), (-3, -3, -1), (8, 0, 0), (0, 8, 0), 64, 64)
+    _check(vrt_ctx, oracle_mod, s, cam2, ra.Params(spp=1, max_depth=3))
