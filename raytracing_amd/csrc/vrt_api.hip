@@ -5,6 +5,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <algorithm>
+#include <utility>
 #include <vector>
 
 #include "vrt_launch.h"
@@ -288,6 +290,45 @@ extern "C" int vrt_set_scene(vrt_ctx* c, const vrt_scene_desc* d)
     c->use_bvh = n_prims > kBruteMaxPrims;
     c->bvh_ms = 0.f; c->bvh_depth = 0;
     if (c->use_bvh) {
+        // Up to VRT_MAX_BIG primitives whose box is at least half as long as the scene's stay
+        // out of the tree (spheres and boxes only; a mesh is expected to be tessellated).
+        // VRT_NO_BIG=1 keeps them in, for study.
+        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+        std::vector<std::pair<double, int>> ext(d->n_spheres + d->n_boxes);
+        auto grow = [&](const double l[3], const double h[3]) {
+            for (int k = 0; k < 3; ++k) { if (l[k] < lo[k]) lo[k] = l[k]; if (h[k] > hi[k]) hi[k] = h[k]; }
+        };
+        for (uint32_t i = 0; i < d->n_spheres; ++i) {
+            const vrt_sphere& s = d->spheres[i];
+            double l[3], h[3];
+            for (int k = 0; k < 3; ++k) { l[k] = s.center[k] - s.radius; h[k] = s.center[k] + s.radius; }
+            grow(l, h);
+            ext[i] = {2.0 * s.radius, (int)i};
+        }
+        for (uint32_t i = 0; i < d->n_boxes; ++i) {
+            const vrt_box& b = d->boxes[i];
+            double l[3], h[3], m = 0;
+            for (int k = 0; k < 3; ++k) {
+                double e = fabs(b.axis[k]) * b.half[0] + fabs(b.axis[3 + k]) * b.half[1] + fabs(b.axis[6 + k]) * b.half[2];
+                l[k] = b.center[k] - e; h[k] = b.center[k] + e;
+                if (2 * e > m) m = 2 * e;
+            }
+            grow(l, h);
+            ext[d->n_spheres + i] = {m, (int)(d->n_spheres + i)};
+        }
+        for (uint32_t i = 0; i < d->n_vertices; ++i) {
+            double v[3] = {d->vertices[3 * (size_t)i], d->vertices[3 * (size_t)i + 1], d->vertices[3 * (size_t)i + 2]};
+            grow(v, v);
+        }
+        double scene_ext = 0;
+        for (int k = 0; k < 3; ++k) if (hi[k] - lo[k] > scene_ext) scene_ext = hi[k] - lo[k];
+        std::sort(ext.begin(), ext.end(), [](const std::pair<double, int>& a, const std::pair<double, int>& b) {
+            return a.first > b.first || (a.first == b.first && a.second < b.second);
+        });
+        const char* nb = getenv("VRT_NO_BIG");
+        if (!(nb && atoi(nb)))
+            for (size_t i = 0; i < ext.size() && S.n_big < VRT_MAX_BIG && ext[i].first >= 0.5 * scene_ext; ++i)
+                S.big[S.n_big++] = ext[i].second;
         HIPCHK(c, hipMalloc(&c->d_bvh, 4 * (size_t)(n_prims - 1) * sizeof(float4)));
         HIPCHK(c, hipMalloc(&c->d_bvh4, 8 * (size_t)(n_prims - 1) * sizeof(float4)));
         S.bvh = c->d_bvh; S.bvh4 = c->d_bvh4;

@@ -56,6 +56,9 @@ __device__ __forceinline__ void prim_box(const DevScene& S, int id, float lo[3],
             hi[k] = fmaxf(p0[k], fmaxf(p1[k], p2[k]));
         }
     }
+    for (int b = 0; b < S.n_big; ++b)
+        if (S.big[b] == id)  // tested ahead of the traversal: only a point in the tree
+            for (int k = 0; k < 3; ++k) lo[k] = hi[k] = 0.5f * (lo[k] + hi[k]);
     for (int k = 0; k < 3; ++k) {
         float e = 1e-4f * (1.f + fmaxf(fabsf(lo[k]), fabsf(hi[k])));
         lo[k] -= e; hi[k] += e;

@@ -20,6 +20,8 @@
 #include <stdint.h>
 #include "../../include/vrt.h"
 
+#define VRT_MAX_BIG 8
+
 struct DevLight {
     int type;
     float vx, vy, vz;
@@ -44,6 +46,11 @@ struct DevScene {
     const float4* cam_pre; // per sphere (o-c, |o-c|^2 - r^2), per box (o-c, 0) for o = camera origin
     int n_lights;
     const DevLight* lights; // n_lights entries in device memory
+    // Primitives whose box spans a large part of the scene (a ground box under 10k spheres) would
+    // inflate every LBVH node above their leaf; they enter the tree as a point at their centre
+    // and are tested ahead of the traversal instead.
+    int n_big;
+    int big[VRT_MAX_BIG];
     unsigned long long* dbg; // the context's counter block (slots 6, 7: nodes entered, primitives tested)
     vrt_shading sh;
 };

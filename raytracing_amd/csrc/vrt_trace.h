@@ -200,7 +200,7 @@ __device__ __forceinline__ void test_prim(const DevScene& S, int id, f3 o, f3 d,
 // CAM: the ray starts at the camera origin and S.cam_pre holds the per-primitive terms that
 // depend only on the origin.
 #ifndef VRT_AAB_CULL
-#define VRT_AAB_CULL 0
+#define VRT_AAB_CULL 1
 #endif
 template <bool CAM>
 __device__ __forceinline__ Hit intersect_brute(const DevScene& S, f3 o, f3 d, float maxd, float tlim, int skip, bool ANY)
@@ -297,6 +297,11 @@ __device__ __forceinline__ Hit intersect_bvh(const DevScene& S, f3 o, f3 d, floa
     Hit best; best.t = INFINITY; best.prim = -1; best.aux = 0;
     if (is_zero3(d)) return best;
     f3 inv = mk3(1.f / d.x, 1.f / d.y, 1.f / d.z);
+    for (int k = 0; k < S.n_big; ++k) {   // scene-sized primitives kept out of the tree
+        const int id = S.big[k];
+        if (id != skip) test_prim(S, id, o, d, maxd, best);
+        if (ANY && best.prim >= 0) { if (best.t < tlim) return best; best.prim = -1; best.t = INFINITY; }
+    }
     int deep[VRT_BVH_STACK - VRT_LDS_STACK];
     int sp = 0;
     int node = 0;
@@ -383,6 +388,12 @@ __device__ __forceinline__ Hit intersect_bvh4(const DevScene& S, f3 o, f3 d, flo
     if (is_zero3(d)) return best;
     const f3 inv = mk3(1.f / d.x, 1.f / d.y, 1.f / d.z);
     const float lim0 = fminf(maxd, tlim);
+    for (int k = 0; k < S.n_big; ++k) {   // scene-sized primitives kept out of the tree
+        const int id = S.big[k];
+        count_lanes(S, 7);
+        if (id != skip) test_prim(S, id, o, d, maxd, best);
+        if (ANY && best.prim >= 0) { if (best.t < tlim) return best; best.prim = -1; best.t = INFINITY; }
+    }
     unsigned long long deep[VRT_BVH4_STACK - VRT_LDS_STACK4];
     int sp = 0;
     int node = 0;
@@ -620,11 +631,15 @@ __device__ __forceinline__ f3 phong_shade(const DevScene& S, const DevParams& P,
             }
             if (!in_shadow) {
                 f3 diff = (cd * kd) * 0.3183098861837906715f;
-                float nda = dot3(n, wo);
-                f3 r = mk3(-wo.x + 2.f * n.x * nda, -wo.y + 2.f * n.y * nda, -wo.z + 2.f * n.z * nda);
-                float rdb = dot3(r, wi);
                 float spec = 0.f;
-                if (rdb > 0.f) spec = (1.f * ks) * powf(rdb, ex);
+                // ks = 0 (the solid material) makes the lobe 0 * pow = 0 for every finite pow,
+                // which a non-negative exponent guarantees here (rdb <= 1 up to rounding)
+                if (!(ks == 0.f && ex >= 0.f)) {
+                    float nda = dot3(n, wo);
+                    f3 r = mk3(-wo.x + 2.f * n.x * nda, -wo.y + 2.f * n.y * nda, -wo.z + 2.f * n.z * nda);
+                    float rdb = dot3(r, wi);
+                    if (rdb > 0.f) spec = (1.f * ks) * powf(rdb, ex);
+                }
                 f3 lam = mk3(diff.x + spec, diff.y + spec, diff.z + spec);
                 f3 world = (mk3(l.cr, l.cg, l.cb) * l.ls) * ndotwi;
                 L = L + lam * world;
@@ -895,11 +910,13 @@ __device__ __forceinline__ f3 light_wi(const DevLight& l, f3 point)
 __device__ __forceinline__ f3 light_term(const DevLight& l, f3 wi, float ndotwi, f3 n, f3 wo, f3 cd, MatK k)
 {
     f3 diff = (cd * k.kd) * 0.3183098861837906715f;
-    float nda = dot3(n, wo);
-    f3 r = mk3(-wo.x + 2.f * n.x * nda, -wo.y + 2.f * n.y * nda, -wo.z + 2.f * n.z * nda);
-    float rdb = dot3(r, wi);
     float spec = 0.f;
-    if (rdb > 0.f) spec = (1.f * k.ks) * powf(rdb, k.ex);
+    if (!(k.ks == 0.f && k.ex >= 0.f)) { // see phong_shade
+        float nda = dot3(n, wo);
+        f3 r = mk3(-wo.x + 2.f * n.x * nda, -wo.y + 2.f * n.y * nda, -wo.z + 2.f * n.z * nda);
+        float rdb = dot3(r, wi);
+        if (rdb > 0.f) spec = (1.f * k.ks) * powf(rdb, k.ex);
+    }
     f3 lam = mk3(diff.x + spec, diff.y + spec, diff.z + spec);
     f3 world = (mk3(l.cr, l.cg, l.cb) * l.ls) * ndotwi;
     return lam * world;
