@@ -69,6 +69,9 @@ def build_workload(name, n_gpus):
         label = f"10k random spheres {w}x{h}, 64 spp jittered, depth 8"
     else:
         raise SystemExit(f"unknown workload {name}")
+    if os.environ.get("VRT_BENCH_DEPTH"):  # study only: the same workload cut at another depth
+        kw["max_depth"] = int(os.environ["VRT_BENCH_DEPTH"])
+        label += f" [depth overridden to {kw['max_depth']}]"
     return scene, cam, offsets, kw, label
 
 
@@ -81,6 +84,27 @@ def algorithmic_flops(scene, rays, pixels):
     queries = sum(int(r) for r in rays[1:])
     shaded = int(rays[abi.VRT_RAY_PRIMARY] + rays[abi.VRT_RAY_REFLECT] + rays[abi.VRT_RAY_TRANSMIT])
     return queries * per_query + shaded * (25 + 30 * len(scene.lights)) + pixels * 12 + shaded * 8
+
+
+def profiled_counters(workload, prefix="r01"):
+    """Issue-side view of the dominant kernel from the rocprofv3 summaries committed under
+    profiles/ (not measured live): share of the chip's vector-ALU issue slots the kernel used
+    (one wave64 instruction occupies a SIMD for 4 cycles; 1024 SIMDs at 2.4 GHz) and the mean
+    fraction of the 64 lanes active per vector instruction."""
+    import csv
+    try:
+        pmc = {r["counter"]: float(r["mean_per_dispatch"])
+               for r in csv.DictReader(open(os.path.join(ROOT, "profiles", f"{prefix}_{workload}_pmc.csv")))}
+        stats = list(csv.DictReader(open(os.path.join(ROOT, "profiles", f"{prefix}_{workload}_kernel_stats.csv"))))
+        avg_ns = next(float(r["AverageNs"]) for r in stats if "k_mega" in r["Name"])
+        insts, lanes = pmc["SQ_INSTS_VALU"], pmc["SQ_THREAD_CYCLES_VALU"]
+        return {"source": f"profiles/{prefix}_{workload}_pmc.csv, profiles/{prefix}_{workload}_kernel_stats.csv",
+                "kernel_avg_us": avg_ns / 1e3,
+                "valu_instructions_per_launch": insts,
+                "valu_issue_frac": insts * 4.0 / (1024 * 2.4e9 * avg_ns * 1e-9),
+                "lane_utilisation": lanes / (insts * 64.0)}
+    except Exception:
+        return None
 
 
 def cpu_baseline(scene, cam, prm):
@@ -344,6 +368,9 @@ def main():
                     "frac": ach / PEAK_HBM_GBPS, "traffic": None, "kernel_ms": kernel_ms,
                     "algorithmic_bytes_per_launch": by,
                     "note": "120 B per ray (ray + hit records) + 20 B per pixel; BVH node traffic not included"}
+        prof = profiled_counters(args.workload)
+        if prof:
+            roof["profiled"] = prof
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:

@@ -41,7 +41,7 @@ struct vrt_ctx {
     size_t rec_px_cap = 0, rec_seg_cap = 0;
     float4* d_px_rgba = nullptr; int* d_px_hit = nullptr;
     // wavefront workspace
-    WfWorkspace wf; size_t wf_pixels = 0; bool wf_two = false;
+    WfWorkspace wf; bool wf_two = false;
     // last call
     uint64_t last_pixels = 0; int last_mode = 0;
     bool timed = false;
@@ -123,9 +123,8 @@ static void free_scene(vrt_ctx* c)
 
 static void free_wf(vrt_ctx* c)
 {
-    hipFree(c->wf.arena); hipFree(c->wf.sum); hipFree(c->wf.lacc); hipFree(c->wf.counts);
+    hipFree(c->wf.arena); hipFree(c->wf.lacc); hipFree(c->wf.counts);
     memset(&c->wf, 0, sizeof c->wf);
-    c->wf_pixels = 0;
 }
 
 extern "C" int vrt_destroy(vrt_ctx* c)
@@ -441,24 +440,29 @@ static int prepare(vrt_ctx* c, const vrt_params* p, DevParams* out)
     return VRT_OK;
 }
 
-static int ensure_wf(vrt_ctx* c, size_t pixels, bool two)
+// Sample slots the wavefront workspace holds at most: a band of rows of the frame is in flight
+// at a time.  64 Mi slots are 1 GiB of radiance slots and 7.5 GiB of queues (twice that with two
+// children per hit); a frame with fewer samples gets a workspace of its own size.
+static const size_t kWfMaxSlots = 64ull << 20;
+
+static int ensure_wf(vrt_ctx* c, size_t slots, bool two)
 {
-    if (c->wf_pixels >= pixels && (c->wf_two || !two)) return VRT_OK;
+    if (c->wf.slots >= slots && (c->wf_two || !two)) return VRT_OK;
     free_wf(c);
-    size_t cap = pixels * (two ? 2 : 1);
+    size_t cap = slots * (two ? 2 : 1);
     HIPCHK(c, hipMalloc(&c->wf.arena, cap * 2 * VRT_QUEUE_ARRAYS * sizeof(float)));
     for (int k = 0; k < 2; ++k) {
         float* b = c->wf.arena + (size_t)k * cap * VRT_QUEUE_ARRAYS;
         RayQueue& q = c->wf.q[k];
         q.ox = b; q.oy = b + cap; q.oz = b + 2 * cap; q.dx = b + 3 * cap; q.dy = b + 4 * cap; q.dz = b + 5 * cap;
         q.tr = b + 6 * cap; q.tg = b + 7 * cap; q.tb = b + 8 * cap;
-        q.pix = (int*)(b + 9 * cap); q.skip = (int*)(b + 10 * cap); q.meta = (int*)(b + 11 * cap);
+        q.lr = b + 9 * cap; q.lg = b + 10 * cap; q.lb = b + 11 * cap;
+        q.pix = (int*)(b + 12 * cap); q.skip = (int*)(b + 13 * cap); q.meta = (int*)(b + 14 * cap);
     }
     c->wf.cap = cap;
-    HIPCHK(c, hipMalloc(&c->wf.sum, pixels * sizeof(float4)));
-    HIPCHK(c, hipMalloc(&c->wf.lacc, pixels * sizeof(float4)));
+    HIPCHK(c, hipMalloc(&c->wf.lacc, slots * sizeof(float4)));
     HIPCHK(c, hipMalloc(&c->wf.counts, (VRT_MAX_DEPTH + 3) * sizeof(int)));
-    c->wf_pixels = pixels; c->wf_two = two;
+    c->wf.slots = slots; c->wf_two = two;
     return VRT_OK;
 }
 
@@ -470,8 +474,14 @@ static int enqueue_frame(vrt_ctx* c, const vrt_params* p, const DevParams& P, fl
     bool two = (p->flags & VRT_FIX_DIELECTRIC) != 0;
     int mode = p->mode == VRT_MODE_WAVEFRONT ? VRT_MODE_WAVEFRONT : VRT_MODE_MEGAKERNEL;
     if (mode == VRT_MODE_WAVEFRONT) {
-        size_t pixels = (size_t)P.local_rows * c->cam.width;
-        int rc = ensure_wf(c, pixels ? pixels : 1, two);
+        // whole frame if it fits the slot budget, else bands of rows of at least one tile row
+        size_t per_row = (size_t)c->cam.width * P.spp;
+        size_t want = per_row * (size_t)(P.local_rows > 0 ? P.local_rows : 1);
+        size_t min_band = per_row * 8;
+        if (want > kWfMaxSlots) want = kWfMaxSlots > min_band ? kWfMaxSlots : min_band;
+        if (want < min_band) want = min_band;
+        if (want * (two ? 2 : 1) > 0x7fffffffull) return fail(c, VRT_ERR_CAPACITY, "frame row too long for the wavefront queues");
+        int rc = ensure_wf(c, want, two);
         if (rc) return rc;
         HIPCHK(c, vrt_launch_wavefront(c->scene, c->cam, P, c->use_bvh, two, c->wf, rgba, hit, c->d_ctr, stream));
     } else {

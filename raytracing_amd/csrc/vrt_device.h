@@ -86,11 +86,12 @@ struct DevParams {
 struct RayQueue {
     float *ox, *oy, *oz, *dx, *dy, *dz; // origin, unit direction
     float *tr, *tg, *tb;                // path throughput
-    int *pix;                           // local pixel index
+    float *lr, *lg, *lb;                // radiance the path has gathered so far
+    int *pix;                           // sample slot = pixel of the band * spp + sample
     int *skip;                          // primitive the ray was spawned on
     int *meta;                          // depth | kind << 8
 };
-#define VRT_QUEUE_ARRAYS 12
+#define VRT_QUEUE_ARRAYS 15
 
 #define VRT_BVH_STACK 64
 #define VRT_BVH4_STACK 96

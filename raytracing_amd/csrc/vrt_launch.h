@@ -14,14 +14,15 @@ hipError_t vrt_launch_ray(const DevScene& S, const DevParams& P, bool bvh, bool 
                           const float d[3], int depth, float4* rgba_out, int* hit_out, unsigned long long* ctr,
                           hipStream_t stream);
 
-// Wavefront pipeline workspace: ray queues (two, ping-pong), per-pixel accumulators, counters.
+// Wavefront pipeline workspace: ray queues (two, ping-pong), one radiance slot per sample of the
+// band of rows in flight, queue counters.
 struct WfWorkspace {
     RayQueue q[2];
     float* arena;       // backing store of both queues
     size_t cap;         // rays per queue
-    float4* sum;        // per local pixel: running sum over samples (xyz)
-    float4* lacc;       // per local pixel: radiance of the sample in flight (xyz), w = hit flag
-    int* counts;        // queue sizes per depth, VRT_MAX_DEPTH + 3 ints
+    size_t slots;       // sample slots (pixels of a band x samples per pixel)
+    float4* lacc;       // per slot: radiance of that sample (xyz)
+    int* counts;        // queue sizes per depth + overflow flag, VRT_MAX_DEPTH + 3 ints
 };
 
 hipError_t vrt_launch_wavefront(const DevScene& S, const DevCam& cam, const DevParams& P, bool bvh,

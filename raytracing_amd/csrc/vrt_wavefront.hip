@@ -1,17 +1,22 @@
-// Wavefront pipeline (gfx950): one kernel per bounce over compacted struct-of-arrays ray
-// queues in HBM, so that lanes whose path has ended do not ride along with live ones.
+// Wavefront pipeline (gfx950): paths that go on after their first hit leave the per-pixel
+// lanes and are traced bounce by bounce from compacted struct-of-arrays ray queues in HBM, so
+// that lanes whose path has ended do not ride along with live ones.
 //
-// Per anti-aliasing sample i:
-//   k_wf_primary  one lane per pixel: folds the previous sample's radiance into the running
-//                 sum, generates the camera ray, finds and shades the primary hit and appends
-//                 the child ray(s) to queue 0.
+// The frame is worked through in bands of rows sized to a fixed number of sample slots
+// (slot = pixel of the band * spp + sample).  Per band:
+//   k_wf_primary  lanes = pixels x samples like the megakernel: camera ray, primary hit and its
+//                 shading (ambient-occlusion and shadow rays included); a path that ends here
+//                 writes its radiance to its slot, one that goes on is appended to queue 0
+//                 together with the radiance gathered so far.
 //   k_wf_bounce   depth d = 1..max_depth: a persistent grid walks queue d-1, traces and shades,
-//                 adds throughput * direct light to the pixel's accumulator and appends the
-//                 survivors to queue d.  Appends are compacted per wave: ballot -> mbcnt prefix
-//                 -> one atomic per wave.
-//   k_wf_resolve  after the last sample: average, tone-map, write the framebuffer.
-// Samples are traced one after the other so that the per-pixel sum is formed in sample order
-// (RayTracerUnity.cs:580-592).
+//                 and either finishes the path (slot write) or appends it to queue d.  Appends
+//                 are compacted per wave: ballot -> mbcnt prefix -> one atomic per wave, which
+//                 also keeps the samples of one pixel next to each other in the queue.
+//   k_wf_resolve  per pixel: sum of its slots in sample order (RayTracerUnity.cs:580-592),
+//                 average, tone-map, framebuffer write.
+// With one child per hit a path owns its slot and carries its radiance in the queue entry, so
+// the arithmetic and its order are those of the megakernel's trace_path.  With two children per
+// hit (VRT_FIX_DIELECTRIC) the branches of a path share the slot and add into it atomically.
 #define VRT_STACK_LANES 256
 #include "vrt_trace.h"
 #include "vrt_launch.h"
@@ -66,85 +71,104 @@ __device__ __forceinline__ int wave_append(bool want, int* counter, int cap, int
     return slot;
 }
 
-__device__ __forceinline__ void queue_store(const RayQueue& q, int slot, f3 o, f3 d, f3 T, int pix, int skip, int meta)
+__device__ __forceinline__ void queue_store(const RayQueue& q, int at, f3 o, f3 d, f3 T, f3 L, int slot, int skip, int meta)
 {
-    q.ox[slot] = o.x; q.oy[slot] = o.y; q.oz[slot] = o.z;
-    q.dx[slot] = d.x; q.dy[slot] = d.y; q.dz[slot] = d.z;
-    q.tr[slot] = T.x; q.tg[slot] = T.y; q.tb[slot] = T.z;
-    q.pix[slot] = pix; q.skip[slot] = skip; q.meta[slot] = meta;
+    q.ox[at] = o.x; q.oy[at] = o.y; q.oz[at] = o.z;
+    q.dx[at] = d.x; q.dy[at] = d.y; q.dz[at] = d.z;
+    q.tr[at] = T.x; q.tg[at] = T.y; q.tb[at] = T.z;
+    q.lr[at] = L.x; q.lg[at] = L.y; q.lb[at] = L.z;
+    q.pix[at] = slot; q.skip[at] = skip; q.meta[at] = meta;
 }
 
-// Shades hit `h` of ray (o, d) at `depth`, returns T*A and appends the children.
+// The part of trace_path's loop body that follows a closest-hit query, for a path at `depth`
+// whose radiance so far is L and throughput T: adds the hit's (or the sky's) term, then either
+// finishes the path into its slot or appends it (them) to the next queue.  `shaded_ray` is false
+// for a primary miss that contributes nothing.  The whole wave must call it.
 template <bool BVH, bool TWOCHILD>
-__device__ __forceinline__ f3 shade_and_spawn(const DevScene& S, const DevParams& P, bool active, Hit h, f3 o, f3 d,
-                                              f3 T, int depth, int pix, const RayQueue& out, int* out_count, int cap,
-                                              int* overflow, Counters& C)
+__device__ __forceinline__ void shade_and_spawn(const DevScene& S, const DevParams& P, bool active, bool shaded_ray,
+                                                Hit h, f3 o, f3 d, f3 T, f3 L, int depth, int slot,
+                                                const WfWorkspace& W, Counters& C)
 {
-    f3 add = mk3(0.f, 0.f, 0.f);
     Bounce B; B.n_child = 0;
     Recorder R; R.segs = nullptr; R.cap = 0; R.n = 0; R.sample = 0;
-    bool hit = active && h.prim >= 0;
+    const bool live = active && shaded_ray;
+    const bool hit = live && h.prim >= 0;
+    f3 add = mk3(0.f, 0.f, 0.f);
     if (hit) {
         shade_hit<BVH, false>(S, P, h, o, d, depth, C, R, B);
         add = T * B.A;
         if (depth + 1 > P.max_depth) B.n_child = 0;
+    } else if (live) {
+        add = T * sky_color(d);
     }
-    int s0 = wave_append(hit && B.n_child >= 1, out_count, cap, overflow);
-    if (s0 >= 0) queue_store(out, s0, B.o, B.d0, T * B.w0, pix, B.prim, (depth + 1) | (VRT_RAY_REFLECT << 8));
+    if (live) L = L + add;
+    const RayQueue& out = W.q[depth & 1];
+    int* overflow = &W.counts[VRT_MAX_DEPTH + 2];
+    int s0 = wave_append(hit && B.n_child >= 1, &W.counts[depth], (int)W.cap, overflow);
+    if (s0 >= 0) queue_store(out, s0, B.o, B.d0, T * B.w0, L, slot, B.prim, (depth + 1) | (VRT_RAY_REFLECT << 8));
     if (TWOCHILD) {
-        int s1 = wave_append(hit && B.n_child == 2, out_count, cap, overflow);
-        if (s1 >= 0) queue_store(out, s1, B.o, B.d1, T * B.w1, pix, B.prim, (depth + 1) | (VRT_RAY_TRANSMIT << 8));
+        int s1 = wave_append(hit && B.n_child == 2, &W.counts[depth], (int)W.cap, overflow);
+        if (s1 >= 0) queue_store(out, s1, B.o, B.d1, T * B.w1, L, slot, B.prim, (depth + 1) | (VRT_RAY_TRANSMIT << 8));
+        if (live) {   // branches share the slot: every term is added where it arises
+            float* a = (float*)&W.lacc[slot];
+            atomicAdd(a, add.x); atomicAdd(a + 1, add.y); atomicAdd(a + 2, add.z);
+        }
+    } else if (active && !(hit && B.n_child >= 1)) {
+        W.lacc[slot] = make_float4(L.x, L.y, L.z, 0.f);   // the path ends here
     }
-    return add;
 }
 
+// Four waves per block (the traversal stack in LDS is sized for 256 lanes); each wave owns one
+// tile, lanes = pixels x samples exactly as in k_mega (same tile shapes).
 template <bool BVH, bool TWOCHILD>
-__global__ __launch_bounds__(256) void k_wf_primary(DevScene S, DevCam cam, DevParams P, WfWorkspace W, int sample,
-                                                    int* __restrict__ hit_id, unsigned long long* ctr, int blocks_x,
-                                                    int n_blocks)
+__global__ __launch_bounds__(256, 4) void k_wf_primary(DevScene S, DevCam cam, DevParams P, WfWorkspace W, int row0,
+                                                       int band_rows, int* __restrict__ hit_id, unsigned long long* ctr,
+                                                       int blocks_x, int n_tiles)
 {
-    unsigned bid = blockIdx.x;
-    {
-        unsigned q = n_blocks / 8, r = n_blocks % 8, xcd = bid % 8, k = bid / 8;
-        if (P.xcd_remap) bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
-    }
-    int bx = bid % blocks_x, by = bid / blocks_x;
-    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    int v = bx * 32 + wave * 8 + (lane & 7);
-    int r = by * 8 + (lane >> 3);
-    int h = local_to_global_row(P, r);
-    bool active = v < cam.width && r < P.local_rows && h < cam.height;
-    int lp = r * cam.width + v;
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int bx = tile % blocks_x, by = tile / blocks_x;
+    const int lane = threadIdx.x & 63;
+    const int shift = P.sample_shift;
+    const int n_sl = 1 << shift;
+    const int pshift = 6 - shift;
+    const int pw_shift = (pshift + 1) >> 1;
+    const int pi = lane >> shift, si = lane & (n_sl - 1);
+    const int v = (bx << pw_shift) + (pi & ((1 << pw_shift) - 1));
+    const int rb = (by << (pshift - pw_shift)) + (pi >> pw_shift); // row within the band
+    const int r = row0 + rb;
+    const int h = local_to_global_row(P, r);
+    const bool inside = tile < n_tiles && v < cam.width && rb < band_rows && r < P.local_rows && h < cam.height;
     Counters C = {0, 0, 0, 0, 0, 0};
-    f3 O = mk3(cam.ox, cam.oy, cam.oz);
-    f3 d = mk3(0.f, 0.f, 0.f);
-    Hit first; first.prim = -1; first.t = INFINITY; first.aux = 0;
-    f3 L = mk3(0.f, 0.f, 0.f);
-    if (active) {
-        if (sample == 0) W.sum[lp] = make_float4(0.f, 0.f, 0.f, 0.f);
-        else {
-            float4 s = W.sum[lp], a = W.lacc[lp];
-            W.sum[lp] = make_float4(s.x + a.x, s.y + a.y, s.z + a.z, 0.f);
-        }
-        f3 raw = camera_raw_dir(cam, h, v);
+    const f3 O = mk3(cam.ox, cam.oy, cam.oz);
+    f3 raw = mk3(0.f, 0.f, 0.f);
+    const float2* off = nullptr;
+    if (inside) {
+        raw = camera_raw_dir(cam, h, v);
         unsigned pixel = (unsigned)(h * cam.width + v);
         unsigned set = pixel_set_dev(P.seed, pixel, (unsigned)P.n_sets);
-        float ox = 0.f, oy = 0.f;
-        if (P.offsets) { float2 q = P.offsets[(size_t)set * P.spp + sample]; ox = q.x; oy = q.y; }
-        d = normalize3(mk3(raw.x + ox, raw.y + oy, raw.z));
-        if (!is_zero3(d)) {
-            C.precheck++;
-            first = intersect<BVH, false, true>(S, O, d, P.range, -1);
-        }
-        if (first.prim >= 0) C.primary++;
-        else if (P.flags & VRT_FIX_PRIMARY_SKY) L = sky_color(d);
-        if (sample == 0 && hit_id) hit_id[(size_t)(P.compact ? r : h) * cam.width + v] = first.prim;
+        off = P.offsets ? P.offsets + (size_t)set * P.spp : nullptr;
     }
-    f3 add = shade_and_spawn<BVH, TWOCHILD>(S, P, active, first, O, d, mk3(1.f, 1.f, 1.f), 0, lp, W.q[0], &W.counts[0],
-                                            (int)W.cap, &W.counts[VRT_MAX_DEPTH + 2], C);
-    if (active) {
-        if (first.prim >= 0) L = add;
-        W.lacc[lp] = make_float4(L.x, L.y, L.z, 0.f);
+    const int slot0 = (rb * cam.width + v) * P.spp;
+    const bool sky = (P.flags & VRT_FIX_PRIMARY_SKY) != 0;
+    for (int base = 0; base < P.spp; base += n_sl) {   // wave-uniform trip count
+        const int i = base + si;
+        const bool active = inside && i < P.spp;
+        f3 d = mk3(0.f, 0.f, 0.f);
+        Hit first; first.prim = -1; first.t = INFINITY; first.aux = 0;
+        if (active) {
+            float ox = 0.f, oy = 0.f;
+            if (off) { float2 q = off[i]; ox = q.x; oy = q.y; }
+            d = normalize3(mk3(raw.x + ox, raw.y + oy, raw.z));
+            if (!is_zero3(d)) {
+                C.precheck++;
+                first = intersect<BVH, false, true>(S, O, d, P.range, -1);
+            }
+            if (first.prim >= 0) C.primary++;
+            if (i == 0 && hit_id) hit_id[(size_t)(P.compact ? r : h) * cam.width + v] = first.prim;
+        }
+        // RayTracerUnity.cs:582-586: a primary miss adds nothing (the sky with VRT_FIX_PRIMARY_SKY)
+        shade_and_spawn<BVH, TWOCHILD>(S, P, active, first.prim >= 0 || sky, first, O, d, mk3(1.f, 1.f, 1.f),
+                                       mk3(0.f, 0.f, 0.f), 0, slot0 + i, W, C);
     }
     flush_counters(C, ctr, blockIdx.x);
 }
@@ -154,7 +178,6 @@ __global__ __launch_bounds__(256) void k_wf_bounce(DevScene S, DevParams P, WfWo
                                                    unsigned long long* ctr)
 {
     const RayQueue& in = W.q[(depth - 1) & 1];
-    const RayQueue& out = W.q[depth & 1];
     int count = W.counts[depth - 1];
     if (count > (int)W.cap) count = (int)W.cap;
     Counters C = {0, 0, 0, 0, 0, 0};
@@ -164,44 +187,37 @@ __global__ __launch_bounds__(256) void k_wf_bounce(DevScene S, DevParams P, WfWo
     for (int base = blockIdx.x * 256 + (threadIdx.x & ~63); base < count; base += stride) {
         int i = base + (threadIdx.x & 63);
         bool active = i < count;
-        f3 o = mk3(0.f, 0.f, 0.f), d = o, T = o;
-        int pix = 0, skip = -1, meta = 0;
+        f3 o = mk3(0.f, 0.f, 0.f), d = o, T = o, L = o;
+        int slot = 0, skip = -1, meta = 0;
         Hit h; h.prim = -1; h.t = INFINITY; h.aux = 0;
         if (active) {
             o = mk3(in.ox[i], in.oy[i], in.oz[i]);
             d = mk3(in.dx[i], in.dy[i], in.dz[i]);
             T = mk3(in.tr[i], in.tg[i], in.tb[i]);
-            pix = in.pix[i]; skip = in.skip[i]; meta = in.meta[i];
+            L = mk3(in.lr[i], in.lg[i], in.lb[i]);
+            slot = in.pix[i]; skip = in.skip[i]; meta = in.meta[i];
             if (!is_zero3(d)) {
                 if ((meta >> 8) == VRT_RAY_REFLECT) C.reflect++; else C.transmit++;
                 h = intersect<BVH, false>(S, o, d, P.range, skip);
             }
         }
-        f3 add = shade_and_spawn<BVH, TWOCHILD>(S, P, active, h, o, d, T, depth, pix, out, &W.counts[depth], (int)W.cap,
-                                                &W.counts[VRT_MAX_DEPTH + 2], C);
-        if (active) {
-            if (h.prim < 0) add = T * sky_color(d);
-            if (TWOCHILD) {
-                float* a = (float*)&W.lacc[pix];
-                atomicAdd(a, add.x); atomicAdd(a + 1, add.y); atomicAdd(a + 2, add.z);
-            } else {
-                float4 a = W.lacc[pix];
-                W.lacc[pix] = make_float4(a.x + add.x, a.y + add.y, a.z + add.z, 0.f);
-            }
-        }
+        shade_and_spawn<BVH, TWOCHILD>(S, P, active, true, h, o, d, T, L, depth, slot, W, C);
     }
     flush_counters(C, ctr, blockIdx.x);
 }
 
-__global__ __launch_bounds__(256) void k_wf_resolve(DevCam cam, DevParams P, WfWorkspace W, float4* __restrict__ rgba)
+__global__ __launch_bounds__(256) void k_wf_resolve(DevCam cam, DevParams P, WfWorkspace W, int row0, int band_rows,
+                                                    float4* __restrict__ rgba)
 {
     int lp = blockIdx.x * 256 + threadIdx.x;
-    if (lp >= P.local_rows * cam.width) return;
-    int r = lp / cam.width, v = lp % cam.width;
+    if (lp >= band_rows * cam.width) return;
+    int rb = lp / cam.width, v = lp % cam.width;
+    int r = row0 + rb;
     int h = local_to_global_row(P, r);
-    if (h >= cam.height) return;
-    float4 s = W.sum[lp], a = W.lacc[lp];
-    f3 sum = mk3(s.x + a.x, s.y + a.y, s.z + a.z);
+    if (r >= P.local_rows || h >= cam.height) return;
+    const float4* a = W.lacc + (size_t)lp * P.spp;
+    f3 sum = mk3(0.f, 0.f, 0.f);
+    for (int i = 0; i < P.spp; ++i) { float4 q = a[i]; sum = sum + mk3(q.x, q.y, q.z); }
     f3 fin = sum / (float)P.spp;
     rgba[(size_t)(P.compact ? r : h) * cam.width + v] = process_color(fin);
 }
@@ -210,21 +226,32 @@ template <bool BVH, bool TWOCHILD>
 hipError_t run(const DevScene& S, const DevCam& cam, const DevParams& P, const WfWorkspace& W, float4* rgba, int* hit_id,
                unsigned long long* ctr, hipStream_t stream)
 {
-    int blocks_x = (cam.width + 31) / 32, blocks_y = (P.local_rows + 7) / 8;
-    int n_blocks = blocks_x * blocks_y;
-    if (n_blocks <= 0) return hipSuccess;
-    size_t pixels = (size_t)P.local_rows * cam.width;
-    int bounce_blocks = (int)((W.cap + 255) / 256);
-    if (bounce_blocks > 2048) bounce_blocks = 2048;
-    for (int s = 0; s < P.spp; ++s) {
+    if (P.local_rows <= 0) return hipSuccess;
+    const int pshift = 6 - P.sample_shift, pw_shift = (pshift + 1) >> 1, ph_shift = pshift - pw_shift;
+    const int blocks_x = (cam.width + (1 << pw_shift) - 1) >> pw_shift;
+    // rows per band: as many as the slot budget holds, a multiple of the tile height
+    const size_t per_row = (size_t)cam.width * P.spp;
+    long long band = (long long)(W.slots / per_row);
+    band = (band >> ph_shift) << ph_shift;
+    if (band < (1 << ph_shift)) return hipErrorInvalidValue; // the workspace holds one tile row at least
+    for (int row0 = 0; row0 < P.local_rows; row0 += (int)band) {
+        const int rows = P.local_rows - row0 < band ? P.local_rows - row0 : (int)band;
+        const int blocks_y = (rows + (1 << ph_shift) - 1) >> ph_shift;
         hipError_t e = hipMemsetAsync(W.counts, 0, (VRT_MAX_DEPTH + 2) * sizeof(int), stream);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((k_wf_primary<BVH, TWOCHILD>), dim3(n_blocks), dim3(256), 0, stream, S, cam, P, W, s, hit_id,
-                           ctr, blocks_x, n_blocks);
+        if (TWOCHILD) {
+            e = hipMemsetAsync(W.lacc, 0, (size_t)rows * per_row * sizeof(float4), stream);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL((k_wf_primary<BVH, TWOCHILD>), dim3((blocks_x * blocks_y + 3) / 4), dim3(256), 0, stream, S, cam,
+                           P, W, row0, rows, hit_id, ctr, blocks_x, blocks_x * blocks_y);
+        size_t live = (size_t)rows * per_row * (TWOCHILD ? 2 : 1);
+        int bounce_blocks = (int)((live + 255) / 256 < 4096 ? (live + 255) / 256 : 4096);
         for (int d = 1; d <= P.max_depth; ++d)
             hipLaunchKernelGGL((k_wf_bounce<BVH, TWOCHILD>), dim3(bounce_blocks), dim3(256), 0, stream, S, P, W, d, ctr);
+        hipLaunchKernelGGL(k_wf_resolve, dim3((unsigned)(((size_t)rows * cam.width + 255) / 256)), dim3(256), 0, stream,
+                           cam, P, W, row0, rows, rgba);
     }
-    hipLaunchKernelGGL(k_wf_resolve, dim3((unsigned)((pixels + 255) / 256)), dim3(256), 0, stream, cam, P, W, rgba);
     return hipGetLastError();
 }
 
@@ -234,7 +261,7 @@ hipError_t vrt_launch_wavefront(const DevScene& S, const DevCam& cam, const DevP
                                 const WfWorkspace& W, float4* rgba, int* hit_id, unsigned long long* ctr,
                                 hipStream_t stream)
 {
-    // the overflow word is cleared once per frame, the per-depth counts once per sample
+    // the overflow word is cleared once per frame, the per-depth counts once per band
     hipError_t e = hipMemsetAsync(W.counts + VRT_MAX_DEPTH + 2, 0, sizeof(int), stream);
     if (e != hipSuccess) return e;
     if (bvh) return twochild ? run<true, true>(S, cam, P, W, rgba, hit_id, ctr, stream)
