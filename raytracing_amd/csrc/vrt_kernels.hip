@@ -27,12 +27,15 @@ __device__ __forceinline__ void flush_counters(const Counters& C, unsigned long 
     __shared__ unsigned s_ctr[VRT_RAY_CLASSES];
     if (threadIdx.x < VRT_RAY_CLASSES) s_ctr[threadIdx.x] = 0;
     __syncthreads();
-    unsigned v[VRT_RAY_CLASSES] = {C.precheck, C.primary, C.reflect, C.transmit, C.shadow, C.ao};
-#pragma unroll
-    for (int k = 0; k < VRT_RAY_CLASSES; ++k) {
-        unsigned s = wave_sum(v[k]);
-        if ((threadIdx.x & 63) == 0 && s) atomicAdd(&s_ctr[k], s);
+    // one field at a time: an indexed local array of the six counts would live in scratch
+#define VRT_FLUSH(K, FIELD)                                               \
+    {                                                                     \
+        unsigned s = wave_sum(C.FIELD);                                   \
+        if ((threadIdx.x & 63) == 0 && s) atomicAdd(&s_ctr[K], s);        \
     }
+    VRT_FLUSH(VRT_RAY_PRECHECK, precheck) VRT_FLUSH(VRT_RAY_PRIMARY, primary) VRT_FLUSH(VRT_RAY_REFLECT, reflect)
+    VRT_FLUSH(VRT_RAY_TRANSMIT, transmit) VRT_FLUSH(VRT_RAY_SHADOW, shadow) VRT_FLUSH(VRT_RAY_AO, ao)
+#undef VRT_FLUSH
     __syncthreads();
     if (threadIdx.x < VRT_RAY_CLASSES && s_ctr[threadIdx.x])
         atomicAdd(&ctr[(block_linear % VRT_CTR_SLOTS) * VRT_CTR_STRIDE + threadIdx.x],
@@ -58,7 +61,7 @@ __device__ __forceinline__ void flush_counters(const Counters& C, unsigned long 
 #ifndef VRT_BVH_WAVES
 #define VRT_BVH_WAVES 4
 #endif
-template <bool BVH, bool TWOCHILD>
+template <bool BVH, bool TWOCHILD, bool SPLIT>
 __global__ __launch_bounds__(VRT_MEGA_THREADS, BVH ? VRT_BVH_WAVES : 4) void k_mega(DevScene S, DevCam cam, DevParams P, float4* __restrict__ rgba,
                                               int* __restrict__ hit_id, unsigned long long* ctr,
                                               int blocks_x, int n_blocks)
@@ -70,11 +73,8 @@ __global__ __launch_bounds__(VRT_MEGA_THREADS, BVH ? VRT_BVH_WAVES : 4) void k_m
     }
     const int bx = bid % blocks_x, by = bid / blocks_x;
     const int lane = threadIdx.x;
-#if VRT_USE_SM
-    const int shift = 0;
-#else
-    const int shift = P.sample_shift;
-#endif
+    // SPLIT = false is the instantiation for one lane per pixel (sample_shift 0)
+    const int shift = (VRT_USE_SM || !SPLIT) ? 0 : P.sample_shift;
     const int n_sl = 1 << shift;                       // sample lanes per pixel
     const int pshift = 6 - shift;                      // log2(pixels per wave)
     const int pw_shift = (pshift + 1) >> 1;            // tile width 2^ceil(pshift/2), height 2^floor(pshift/2)
@@ -212,7 +212,8 @@ hipError_t vrt_launch_mega(const DevScene& S, const DevCam& cam, const DevParams
     int n_blocks = blocks_x * blocks_y;
     if (n_blocks <= 0) return hipSuccess;
     dim3 grid(n_blocks), block(VRT_MEGA_THREADS);
-#define VRT_GO(B, T) hipLaunchKernelGGL((k_mega<B, T>), grid, block, 0, stream, S, cam, P, rgba, hit_id, ctr, blocks_x, n_blocks)
+#define VRT_GO(B, T) do { if (shift == 0) hipLaunchKernelGGL((k_mega<B, T, false>), grid, block, 0, stream, S, cam, P, rgba, hit_id, ctr, blocks_x, n_blocks); \
+                         else hipLaunchKernelGGL((k_mega<B, T, true>), grid, block, 0, stream, S, cam, P, rgba, hit_id, ctr, blocks_x, n_blocks); } while (0)
     if (bvh) { if (twochild) VRT_GO(true, true); else VRT_GO(true, false); }
     else     { if (twochild) VRT_GO(false, true); else VRT_GO(false, false); }
 #undef VRT_GO

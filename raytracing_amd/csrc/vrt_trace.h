@@ -685,23 +685,24 @@ __device__ __forceinline__ void shade_hit(const DevScene& S, const DevParams& P,
     int mtype = __float_as_int(m.w);
     f3 cd = mk3(m.x, m.y, m.z);
     const vrt_shading& sh = S.sh;
-    B.prim = h.prim; B.o = point; B.n_child = 0;
+    int n_child = 0;
+    f3 A = mk3(0.f, 0.f, 0.f), d0 = A, w0 = A, d1 = A, w1 = A;
     if (mtype == VRT_MAT_METAL) {
-        B.A = phong_shade<BVH, RECORD>(S, P, point, n, h.prim, d, depth, sh.metal_ka, sh.metal_kd,
+        A = phong_shade<BVH, RECORD>(S, P, point, n, h.prim, d, depth, sh.metal_ka, sh.metal_kd,
                                        sh.metal_ks, sh.metal_exp, cd, C, R);
         f3 wo = -d;
         float ndotwo = dot3(n, wo);
         f3 wi = (-wo) + (n * 2.f) * ndotwo;
         float nd = dot3(n, wi);
         f3 fr = (mk3(sh.metal_cr[0], sh.metal_cr[1], sh.metal_cr[2]) * sh.metal_kr) / fabsf(nd);
-        B.n_child = 1; B.d0 = normalize3(wi); B.w0 = fr * nd;
+        n_child = 1; d0 = normalize3(wi); w0 = fr * nd;
     } else if (mtype == VRT_MAT_DIELECTRIC) {
-        B.A = phong_shade<BVH, RECORD>(S, P, point, n, h.prim, d, depth, sh.glass_ka, sh.glass_kd,
+        A = phong_shade<BVH, RECORD>(S, P, point, n, h.prim, d, depth, sh.glass_ka, sh.glass_kd,
                                        sh.glass_ks, sh.glass_exp, cd, C, R);
         f3 wo = -d;
         float ndotwo = dot3(n, wo);
         f3 wi = (-wo) + (n * 2.f) * ndotwo;
-        B.n_child = 1; B.d0 = normalize3(wi); B.w0 = mk3(1.f, 1.f, 1.f);
+        n_child = 1; d0 = normalize3(wi); w0 = mk3(1.f, 1.f, 1.f);
         if (P.flags & VRT_FIX_DIELECTRIC) {
             float eta = sh.glass_eta_in / sh.glass_eta_out;
             float ci = dot3(n, wo);
@@ -716,14 +717,15 @@ __device__ __forceinline__ void shade_hit(const DevScene& S, const DevParams& P,
                 float ndotwi = dot3(n, wi), ndotwt = dot3(n, wt);
                 float wr = (kr / fabsf(ndotwi)) * fabsf(ndotwi);
                 float wtt = (kt / (eta * eta) / fabsf(ndotwt)) * fabsf(ndotwt);
-                B.w0 = mk3(wr, wr, wr);
-                B.n_child = 2; B.d1 = normalize3(wt); B.w1 = mk3(wtt, wtt, wtt);
+                w0 = mk3(wr, wr, wr);
+                n_child = 2; d1 = normalize3(wt); w1 = mk3(wtt, wtt, wtt);
             }
         }
     } else {
-        B.A = phong_shade<BVH, RECORD>(S, P, point, n, h.prim, d, depth, sh.solid_ka, sh.solid_kd,
+        A = phong_shade<BVH, RECORD>(S, P, point, n, h.prim, d, depth, sh.solid_ka, sh.solid_kd,
                                        sh.solid_ks, sh.solid_exp, cd, C, R);
     }
+    B.prim = h.prim; B.o = point; B.n_child = n_child; B.A = A; B.d0 = d0; B.w0 = w0; B.d1 = d1; B.w1 = w1;
 }
 
 // RayTracerUnity.cs:486-517 + AntiAliasingStrategy.cs:89-90
@@ -779,7 +781,7 @@ __device__ __forceinline__ f3 trace_path(const DevScene& S, const DevParams& P, 
             shade_hit<BVH, RECORD>(S, P, h, o, d, depth, C, R, B);
             L = L + T * B.A;
             if (B.n_child > 0 && depth + 1 <= P.max_depth) {
-                if (TWOCHILD && B.n_child == 2 && sp < VRT_MAX_DEPTH + 2) {
+                if constexpr (TWOCHILD) if (B.n_child == 2 && sp < VRT_MAX_DEPTH + 2) {
                     PendingRay& q = stack[sp++];
                     q.o = B.o; q.d = B.d1; q.T = T * B.w1; q.depth = depth + 1; q.skip = B.prim;
                     q.kind = VRT_RAY_TRANSMIT;
@@ -789,9 +791,13 @@ __device__ __forceinline__ f3 trace_path(const DevScene& S, const DevParams& P, 
             }
         }
         if (!cont) {
-            if (!TWOCHILD || sp == 0) break;
-            PendingRay& q = stack[--sp];
-            o = q.o; d = q.d; T = q.T; depth = q.depth; skip = q.skip; kind = q.kind;
+            if constexpr (TWOCHILD) {
+                if (sp == 0) break;
+                PendingRay& q = stack[--sp];
+                o = q.o; d = q.d; T = q.T; depth = q.depth; skip = q.skip; kind = q.kind;
+            } else {
+                break;
+            }
         }
     }
     return L;

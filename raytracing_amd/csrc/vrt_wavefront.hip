@@ -41,12 +41,15 @@ __device__ __forceinline__ void flush_counters(const Counters& C, unsigned long 
     __shared__ unsigned s_ctr[VRT_RAY_CLASSES];
     if (threadIdx.x < VRT_RAY_CLASSES) s_ctr[threadIdx.x] = 0;
     __syncthreads();
-    unsigned v[VRT_RAY_CLASSES] = {C.precheck, C.primary, C.reflect, C.transmit, C.shadow, C.ao};
-#pragma unroll
-    for (int k = 0; k < VRT_RAY_CLASSES; ++k) {
-        unsigned s = wave_sum(v[k]);
-        if ((threadIdx.x & 63) == 0 && s) atomicAdd(&s_ctr[k], s);
+    // one field at a time: an indexed local array of the six counts would live in scratch
+#define VRT_FLUSH(K, FIELD)                                               \
+    {                                                                     \
+        unsigned s = wave_sum(C.FIELD);                                   \
+        if ((threadIdx.x & 63) == 0 && s) atomicAdd(&s_ctr[K], s);        \
     }
+    VRT_FLUSH(VRT_RAY_PRECHECK, precheck) VRT_FLUSH(VRT_RAY_PRIMARY, primary) VRT_FLUSH(VRT_RAY_REFLECT, reflect)
+    VRT_FLUSH(VRT_RAY_TRANSMIT, transmit) VRT_FLUSH(VRT_RAY_SHADOW, shadow) VRT_FLUSH(VRT_RAY_AO, ao)
+#undef VRT_FLUSH
     __syncthreads();
     if (threadIdx.x < VRT_RAY_CLASSES && s_ctr[threadIdx.x])
         atomicAdd(&ctr[(block_linear % VRT_CTR_SLOTS) * VRT_CTR_STRIDE + threadIdx.x],
