@@ -266,6 +266,63 @@ __global__ __launch_bounds__(256) void k_collapse4(int n_inner, const float4* __
     w[7] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
+// Surface-area-guided 4-wide collapse, one lane per node of the current wide level: the node
+// starts from its two binary children and, while it has a free slot, opens the inner child with
+// the largest box (Wald et al.'s greedy collapse).  Inner children that are left become the
+// wide nodes of the next level (appended to out_q).  A wide node keeps its binary index.
+__global__ __launch_bounds__(256) void k_collapse4_level(const float4* __restrict__ nodes, float4* __restrict__ wide,
+                                                         const int* __restrict__ in_q, int n_in,
+                                                         int* __restrict__ out_q, int* __restrict__ out_count)
+{
+    int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_in) return;
+    const int x = in_q[t];
+    float lo[4][3], hi[4][3];
+    int code[4];
+    int m = 2;
+    {
+        const float4* nd = nodes + 4 * (size_t)x;
+        float4 a0 = nd[0], a1 = nd[1], a2 = nd[2], a3 = nd[3];
+        lo[0][0] = a0.x; lo[0][1] = a0.y; lo[0][2] = a0.z; hi[0][0] = a0.w; hi[0][1] = a1.x; hi[0][2] = a1.y;
+        lo[1][0] = a1.z; lo[1][1] = a1.w; lo[1][2] = a2.x; hi[1][0] = a2.y; hi[1][1] = a2.z; hi[1][2] = a2.w;
+        code[0] = __float_as_int(a3.x); code[1] = __float_as_int(a3.y);
+    }
+    while (m < 4) {
+        int best = -1;
+        float best_area = -1.f;
+        for (int k = 0; k < m; ++k) {
+            if (code[k] < 0) continue;
+            float dx = hi[k][0] - lo[k][0], dy = hi[k][1] - lo[k][1], dz = hi[k][2] - lo[k][2];
+            float area = dx * dy + dy * dz + dz * dx;
+            if (area > best_area) { best_area = area; best = k; }
+        }
+        if (best < 0) break;
+        const float4* cd = nodes + 4 * (size_t)code[best];
+        float4 c0 = cd[0], c1 = cd[1], c2 = cd[2], c3 = cd[3];
+        lo[best][0] = c0.x; lo[best][1] = c0.y; lo[best][2] = c0.z; hi[best][0] = c0.w; hi[best][1] = c1.x; hi[best][2] = c1.y;
+        code[best] = __float_as_int(c3.x);
+        lo[m][0] = c1.z; lo[m][1] = c1.w; lo[m][2] = c2.x; hi[m][0] = c2.y; hi[m][1] = c2.z; hi[m][2] = c2.w;
+        code[m] = __float_as_int(c3.y);
+        ++m;
+    }
+    for (int k = 0; k < m; ++k)
+        if (code[k] >= 0) out_q[atomicAdd(out_count, 1)] = code[k];
+    for (; m < 4; ++m) {
+        for (int k = 0; k < 3; ++k) { lo[m][k] = INFINITY; hi[m][k] = INFINITY; } // see k_collapse4
+        code[m] = VRT_BVH4_EMPTY;
+    }
+    float4* w = wide + 8 * (size_t)x;
+    w[0] = make_float4(lo[0][0], lo[1][0], lo[2][0], lo[3][0]);
+    w[1] = make_float4(lo[0][1], lo[1][1], lo[2][1], lo[3][1]);
+    w[2] = make_float4(lo[0][2], lo[1][2], lo[2][2], lo[3][2]);
+    w[3] = make_float4(hi[0][0], hi[1][0], hi[2][0], hi[3][0]);
+    w[4] = make_float4(hi[0][1], hi[1][1], hi[2][1], hi[3][1]);
+    w[5] = make_float4(hi[0][2], hi[1][2], hi[2][2], hi[3][2]);
+    w[6] = make_float4(__int_as_float(code[0]), __int_as_float(code[1]), __int_as_float(code[2]),
+                       __int_as_float(code[3]));
+    w[7] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 } // namespace
 
 #define BCHK(expr) do { e = (expr); if (e != hipSuccess) goto done; } while (0)
@@ -311,7 +368,31 @@ hipError_t vrt_build_lbvh(const DevScene& S, float4* nodes, float4* wide, int* d
     hipLaunchKernelGGL(k_fit, dim3(blocks), dim3(256), 0, stream, n, vals2, pbox, child, parent, leaf_parent, arrived,
                        parked, nodes);
     hipLaunchKernelGGL(k_depth, dim3(blocks), dim3(256), 0, stream, n, parent, leaf_parent, depth);
-    hipLaunchKernelGGL(k_collapse4, dim3((n - 1 + 255) / 256), dim3(256), 0, stream, n - 1, nodes, parent, wide);
+    {
+        // Greedy collapse level by level (the number of levels bounds the traversal stack: three
+        // pushes per level); trees too deep for the stack fall back to the every-second-level
+        // collapse, whose depth is half the binary depth.  `child`/`arrived` are free by now and
+        // serve as the two level queues.
+        int* q0 = (int*)child;
+        int* q1 = q0 + (n - 1);
+        int* qcount = (int*)arrived;
+        int n_in = 1, levels = 0, root = 0;
+        const char* par = getenv("VRT_COLLAPSE_PARITY");
+        bool greedy = !(par && atoi(par));
+        BCHK(hipMemcpyAsync(q0, &root, sizeof(int), hipMemcpyHostToDevice, stream));
+        while (greedy && n_in > 0) {
+            if (3 * (levels + 1) + 1 > VRT_BVH4_STACK) { greedy = false; break; }
+            BCHK(hipMemsetAsync(qcount, 0, sizeof(int), stream));
+            hipLaunchKernelGGL(k_collapse4_level, dim3((n_in + 255) / 256), dim3(256), 0, stream, nodes, wide, q0, n_in, q1,
+                               qcount);
+            BCHK(hipMemcpyAsync(&n_in, qcount, sizeof(int), hipMemcpyDeviceToHost, stream));
+            BCHK(hipStreamSynchronize(stream));
+            int* tq = q0; q0 = q1; q1 = tq;
+            ++levels;
+        }
+        if (!greedy)
+            hipLaunchKernelGGL(k_collapse4, dim3((n - 1 + 255) / 256), dim3(256), 0, stream, n - 1, nodes, parent, wide);
+    }
     BCHK(hipEventRecord(e1, stream));
     BCHK(hipGetLastError());
     BCHK(hipStreamSynchronize(stream));
