@@ -237,6 +237,17 @@ int vrt_set_camera(vrt_ctx* ctx, const vrt_camera* cam);
 int vrt_render(vrt_ctx* ctx, const vrt_params* params, float* rgba_out,
                int32_t* hit_id_out, vrt_stats* stats_out);
 
+/* The same frame without blocking the caller: begin enqueues the frame and the copies into
+ * rgba_out / hit_id_out (which must stay valid, and should be page-locked for the copies to
+ * overlap host work, until vrt_render_end), poll reports completion without waiting, end waits
+ * and returns the statistics.  Lets the host keep rendering its own (VR) frames while a traced
+ * frame is in flight instead of yielding once per sample (RayTracerUnity.cs:333-337,588); with
+ * tile_index/tile_count the frame can also be delivered strip by strip.  No other call on the
+ * context between begin and end except poll; path recording needs the blocking vrt_render. */
+int vrt_render_begin(vrt_ctx* ctx, const vrt_params* params, float* rgba_out, int32_t* hit_id_out);
+int vrt_render_poll(vrt_ctx* ctx, int* done);
+int vrt_render_end(vrt_ctx* ctx, vrt_stats* stats_out);
+
 /* Same, with the outputs left in device memory (rgba_dev, hit_id_dev are device pointers
  * on the context's GPU; hit_id_dev may be NULL).  stream = a hipStream_t or NULL.  The call
  * enqueues and returns; stats_out (may be NULL) is then complete only for gpu_ms = 0 and

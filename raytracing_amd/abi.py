@@ -103,6 +103,6 @@ class vrt_stats(C.Structure):
 EXPORTS = (
     "vrt_create", "vrt_destroy", "vrt_last_error", "vrt_shading_defaults",
     "vrt_params_defaults", "vrt_set_scene", "vrt_set_camera", "vrt_render",
-    "vrt_render_device", "vrt_fetch_stats", "vrt_trace_pixel", "vrt_trace_ray", "vrt_sampler_table",
+    "vrt_render_begin", "vrt_render_poll", "vrt_render_end", "vrt_render_device", "vrt_fetch_stats", "vrt_trace_pixel", "vrt_trace_ray", "vrt_sampler_table",
     "vrt_pixel_set", "vrt_abi_version",
 )

@@ -19,7 +19,8 @@ struct vrt_ctx {
     int device = 0;
     std::string err;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_done = nullptr;
+    bool pending = false; // a vrt_render_begin frame is in flight
     // scene
     float4 *d_sph = nullptr, *d_box = nullptr, *d_tri = nullptr, *d_mat = nullptr, *d_bvh = nullptr, *d_bvh4 = nullptr;
     int* d_prim_mat = nullptr;
@@ -99,6 +100,7 @@ extern "C" int vrt_create(int device, vrt_ctx** out)
     memset(&c->wf, 0, sizeof c->wf);
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming) != hipSuccess ||
         hipMalloc(&c->d_ctr, VRT_CTR_SLOTS * VRT_CTR_STRIDE * sizeof(unsigned long long)) != hipSuccess ||
         hipMalloc(&c->d_px_rgba, sizeof(float4)) != hipSuccess ||
         hipMalloc(&c->d_px_hit, sizeof(int)) != hipSuccess) {
@@ -137,7 +139,7 @@ extern "C" int vrt_destroy(vrt_ctx* c)
     hipFree(c->d_offsets); hipFree(c->d_ctr); hipFree(c->d_rgba); hipFree(c->d_hit);
     hipFree(c->d_rec_pixels); hipFree(c->d_segs); hipFree(c->d_seg_counts);
     hipFree(c->d_px_rgba); hipFree(c->d_px_hit);
-    hipEventDestroy(c->ev0); hipEventDestroy(c->ev1);
+    hipEventDestroy(c->ev0); hipEventDestroy(c->ev1); hipEventDestroy(c->ev_done);
     hipStreamDestroy(c->stream);
     delete c;
     return VRT_OK;
@@ -203,6 +205,7 @@ static int refresh_cam_pre(vrt_ctx* c)
 extern "C" int vrt_set_scene(vrt_ctx* c, const vrt_scene_desc* d)
 {
     if (!c || !d) return fail(c, VRT_ERR_INVALID, "null argument");
+    if (c->pending) return fail(c, VRT_ERR_STATE, "a frame started with vrt_render_begin is still in flight");
     if ((d->n_spheres && !d->spheres) || (d->n_boxes && !d->boxes) ||
         (d->n_triangles && (!d->indices || !d->vertices)) || !d->n_materials || !d->materials ||
         (d->n_lights && !d->lights))
@@ -361,6 +364,7 @@ extern "C" int vrt_set_scene(vrt_ctx* c, const vrt_scene_desc* d)
 extern "C" int vrt_set_camera(vrt_ctx* c, const vrt_camera* cam)
 {
     if (!c || !cam) return fail(c, VRT_ERR_INVALID, "null argument");
+    if (c->pending) return fail(c, VRT_ERR_STATE, "a frame started with vrt_render_begin is still in flight");
     if (cam->width <= 0 || cam->height <= 0 || (int64_t)cam->width * cam->height > (1ll << 30))
         return fail(c, VRT_ERR_INVALID, "frame size out of range");
     DevCam& d = c->cam;
@@ -555,15 +559,14 @@ static int run_records(vrt_ctx* c, const vrt_params* p, const DevParams& P, cons
     return VRT_OK;
 }
 
-extern "C" int vrt_render(vrt_ctx* c, const vrt_params* p, float* rgba_out, int32_t* hit_id_out, vrt_stats* stats_out)
+// Enqueues one frame and its copies to the caller's buffers on the context's stream.
+static int begin_frame(vrt_ctx* c, const vrt_params* p, float* rgba_out, int32_t* hit_id_out, DevParams* P_out)
 {
-    if (!c || !p || !rgba_out) return fail(c, VRT_ERR_INVALID, "null argument");
+    if (c->pending) return fail(c, VRT_ERR_STATE, "a frame started with vrt_render_begin is still in flight");
     HIPCHK(c, hipSetDevice(c->device));
-    DevParams P;
+    DevParams& P = *P_out;
     int rc = prepare(c, p, &P);
     if (rc) return rc;
-    if (p->n_record_pixels < 0 || (p->n_record_pixels > 0 && (!p->record_pixels || !p->record_count_out)))
-        return fail(c, VRT_ERR_INVALID, "record arguments missing");
     size_t npix = (size_t)c->cam.width * c->cam.height;
     if (npix > c->fb_cap) {
         hipFree(c->d_rgba); hipFree(c->d_hit);
@@ -586,6 +589,17 @@ extern "C" int vrt_render(vrt_ctx* c, const vrt_params* p, float* rgba_out, int3
     HIPCHK(c, hipMemcpyAsync(rgba_out, c->d_rgba, nout * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
     if (hit_id_out)
         HIPCHK(c, hipMemcpyAsync(hit_id_out, c->d_hit, nout * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    return VRT_OK;
+}
+
+extern "C" int vrt_render(vrt_ctx* c, const vrt_params* p, float* rgba_out, int32_t* hit_id_out, vrt_stats* stats_out)
+{
+    if (!c || !p || !rgba_out) return fail(c, VRT_ERR_INVALID, "null argument");
+    if (p->n_record_pixels < 0 || (p->n_record_pixels > 0 && (!p->record_pixels || !p->record_count_out)))
+        return fail(c, VRT_ERR_INVALID, "record arguments missing");
+    DevParams P;
+    int rc = begin_frame(c, p, rgba_out, hit_id_out, &P);
+    if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (stats_out) { rc = read_stats(c, stats_out); if (rc) return rc; }
     if (p->n_record_pixels > 0) {
@@ -596,9 +610,44 @@ extern "C" int vrt_render(vrt_ctx* c, const vrt_params* p, float* rgba_out, int3
     return VRT_OK;
 }
 
+extern "C" int vrt_render_begin(vrt_ctx* c, const vrt_params* p, float* rgba_out, int32_t* hit_id_out)
+{
+    if (!c || !p || !rgba_out) return fail(c, VRT_ERR_INVALID, "null argument");
+    if (p->n_record_pixels != 0) return fail(c, VRT_ERR_INVALID, "path recording needs the blocking vrt_render");
+    DevParams P;
+    int rc = begin_frame(c, p, rgba_out, hit_id_out, &P);
+    if (rc) return rc;
+    HIPCHK(c, hipEventRecord(c->ev_done, c->stream));
+    c->pending = true;
+    return VRT_OK;
+}
+
+extern "C" int vrt_render_poll(vrt_ctx* c, int* done)
+{
+    if (!c || !done) return fail(c, VRT_ERR_INVALID, "null argument");
+    if (!c->pending) return fail(c, VRT_ERR_STATE, "no frame in flight");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipError_t e = hipEventQuery(c->ev_done);
+    if (e == hipSuccess) { *done = 1; return VRT_OK; }
+    if (e == hipErrorNotReady) { *done = 0; (void)hipGetLastError(); return VRT_OK; }
+    return fail(c, VRT_ERR_HIP, std::string("hipEventQuery: ") + hipGetErrorString(e));
+}
+
+extern "C" int vrt_render_end(vrt_ctx* c, vrt_stats* stats_out)
+{
+    if (!c) return VRT_ERR_INVALID;
+    if (!c->pending) return fail(c, VRT_ERR_STATE, "no frame in flight");
+    HIPCHK(c, hipSetDevice(c->device));
+    c->pending = false;
+    HIPCHK(c, hipEventSynchronize(c->ev_done));
+    if (stats_out) return read_stats(c, stats_out);
+    return VRT_OK;
+}
+
 extern "C" int vrt_render_device(vrt_ctx* c, const vrt_params* p, void* rgba_dev, void* hit_id_dev, void* stream)
 {
     if (!c || !p || !rgba_dev) return fail(c, VRT_ERR_INVALID, "null argument");
+    if (c->pending) return fail(c, VRT_ERR_STATE, "a frame started with vrt_render_begin is still in flight");
     HIPCHK(c, hipSetDevice(c->device));
     DevParams P;
     int rc = prepare(c, p, &P);
@@ -619,6 +668,7 @@ extern "C" int vrt_trace_pixel(vrt_ctx* c, const vrt_params* p, int h, int v, in
                                int cap, int* n_out, float rgba[4], int32_t* hit_id_out)
 {
     if (!c || !p || !rgba) return fail(c, VRT_ERR_INVALID, "null argument");
+    if (c->pending) return fail(c, VRT_ERR_STATE, "a frame started with vrt_render_begin is still in flight");
     HIPCHK(c, hipSetDevice(c->device));
     DevParams P;
     int rc = prepare(c, p, &P);
@@ -644,6 +694,7 @@ extern "C" int vrt_trace_ray(vrt_ctx* c, const vrt_params* p, const float origin
                              int depth, float rgba[4], int32_t* hit_id_out)
 {
     if (!c || !p || !origin || !direction || !rgba) return fail(c, VRT_ERR_INVALID, "null argument");
+    if (c->pending) return fail(c, VRT_ERR_STATE, "a frame started with vrt_render_begin is still in flight");
     if (depth < 0) return fail(c, VRT_ERR_INVALID, "negative depth");
     HIPCHK(c, hipSetDevice(c->device));
     DevParams P;

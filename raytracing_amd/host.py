@@ -52,6 +52,12 @@ def load_library():
     L.vrt_set_camera.argtypes = [vp, C.POINTER(abi.vrt_camera)]
     L.vrt_render.restype = C.c_int
     L.vrt_render.argtypes = [vp, C.POINTER(abi.vrt_params), vp, vp, C.POINTER(abi.vrt_stats)]
+    L.vrt_render_begin.restype = C.c_int
+    L.vrt_render_begin.argtypes = [vp, C.POINTER(abi.vrt_params), vp, vp]
+    L.vrt_render_poll.restype = C.c_int
+    L.vrt_render_poll.argtypes = [vp, C.POINTER(C.c_int)]
+    L.vrt_render_end.restype = C.c_int
+    L.vrt_render_end.argtypes = [vp, C.POINTER(abi.vrt_stats)]
     L.vrt_render_device.restype = C.c_int
     L.vrt_render_device.argtypes = [vp, C.POINTER(abi.vrt_params), vp, vp, vp]
     L.vrt_fetch_stats.restype = C.c_int
@@ -136,6 +142,21 @@ class Context:
         self._chk(self._lib.vrt_render(self._h, C.byref(params.c), rgba.ctypes.data,
                                        hit.ctypes.data, C.byref(st)))
         return rgba, hit, st
+
+    def render_begin(self, params, rgba, hit=None):
+        """Starts a frame into the given host arrays (keep them alive until render_end)."""
+        self._chk(self._lib.vrt_render_begin(self._h, C.byref(params.c), rgba.ctypes.data,
+                                             hit.ctypes.data if hit is not None else None))
+
+    def render_poll(self):
+        done = C.c_int(0)
+        self._chk(self._lib.vrt_render_poll(self._h, C.byref(done)))
+        return bool(done.value)
+
+    def render_end(self):
+        st = abi.vrt_stats()
+        self._chk(self._lib.vrt_render_end(self._h, C.byref(st)))
+        return st
 
     def render_device(self, params, rgba_ptr, hit_ptr=None, stream=None):
         """Enqueues a frame whose outputs stay in device memory (raw device pointers)."""

@@ -1,0 +1,75 @@
+"""Non-blocking frame API: begin / poll / end must deliver exactly the frame vrt_render delivers,
+strip by strip if asked, and must refuse other work on the context while a frame is in flight."""
+import time
+
+import numpy as np
+import pytest
+
+import raytracing_amd as ra
+from raytracing_amd import abi, host
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(ctx):
+    scene, cam = ra.random_spheres_scene(2000, seed=9), ra.random_spheres_camera(320, 200)
+    ctx.set_scene(scene)
+    ctx.set_camera(cam)
+    offs = host.sampler_table(abi.VRT_SAMPLER_JITTERED, 4, 7, 0.01, 0.01, seed=2)
+    return dict(spp=4, offsets=offs, seed=3, max_depth=5, rng=200.0)
+
+
+def test_begin_poll_end_equals_render(vrt_ctx):
+    kw = _setup(vrt_ctx)
+    ref, ref_hit, ref_st = vrt_ctx.render(ra.Params(**kw))
+    rgba = np.zeros_like(ref)
+    hit = np.zeros_like(ref_hit)
+    prm = ra.Params(**kw)
+    vrt_ctx.render_begin(prm, rgba, hit)
+    polls = 0
+    deadline = time.time() + 60
+    while not vrt_ctx.render_poll():
+        polls += 1
+        assert time.time() < deadline
+    st = vrt_ctx.render_end()
+    assert np.array_equal(rgba, ref, equal_nan=True) and np.array_equal(hit, ref_hit)
+    assert list(st.rays) == list(ref_st.rays) and st.gpu_ms > 0
+
+
+def test_calls_are_refused_while_a_frame_is_in_flight(vrt_ctx):
+    kw = _setup(vrt_ctx)
+    rgba = np.zeros((200, 320, 4), np.float32)
+    prm = ra.Params(**kw)
+    vrt_ctx.render_begin(prm, rgba)
+    for call in (lambda: vrt_ctx.render_begin(prm, rgba), lambda: vrt_ctx.render(prm),
+                 lambda: vrt_ctx.trace_pixel(prm, 1, 1), lambda: vrt_ctx.set_camera(vrt_ctx.cam)):
+        with pytest.raises(host.VrtError) as e:
+            call()
+        assert e.value.code == abi.VRT_ERR_STATE
+    vrt_ctx.render_end()
+    with pytest.raises(host.VrtError) as e:
+        vrt_ctx.render_end()
+    assert e.value.code == abi.VRT_ERR_STATE
+    with pytest.raises(host.VrtError):
+        vrt_ctx.render_poll()
+    ref, _, _ = vrt_ctx.render(prm)
+    assert np.array_equal(rgba, ref, equal_nan=True)
+
+
+def test_progressive_strips(vrt_ctx):
+    """The frame delivered strip by strip (one begin/end per strip set) into one buffer equals the
+    frame rendered at once; rows of later strips stay untouched until their turn."""
+    kw = _setup(vrt_ctx)
+    ref, ref_hit, _ = vrt_ctx.render(ra.Params(**kw))
+    rgba = np.full_like(ref, -1.0)
+    hit = np.full_like(ref_hit, -7)
+    n = 5
+    for k in range(n):
+        prm = ra.Params(tile_index=k, tile_count=n, tile_rows=8, **kw)
+        vrt_ctx.render_begin(prm, rgba, hit)
+        vrt_ctx.render_end()
+        rows_done = [h for h in range(200) if (h // 8) % n <= k]
+        rows_left = [h for h in range(200) if (h // 8) % n > k]
+        assert np.array_equal(rgba[rows_done], ref[rows_done], equal_nan=True)
+        assert (rgba[rows_left] == -1.0).all() and (hit[rows_left] == -7).all()
+    assert np.array_equal(hit, ref_hit)
