@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define VRT_ABI_VERSION 2
+#define VRT_ABI_VERSION 3
 
 typedef struct vrt_ctx vrt_ctx;
 
@@ -125,6 +125,15 @@ typedef struct vrt_shading {
     float ao_color[4];
 } vrt_shading;
 
+/* Material.mainTexture as the tracer reads it (Tracer/WhittedTracer.cs:55-63): a hit on a
+ * textured material returns texture.GetPixel(floor(u*width), floor(v*height)) unshaded.
+ * rgba = width*height*4 floats, row 0 first (Unity's texture origin is the lower left). */
+typedef struct vrt_texture {
+    int32_t width, height;
+    int32_t wrap;        /* TextureWrapMode for out-of-range pixels: 0 = Repeat, 1 = Clamp */
+    const float* rgba;
+} vrt_texture;
+
 typedef struct vrt_scene_desc {
     uint32_t n_spheres;
     const vrt_sphere* spheres;
@@ -142,6 +151,12 @@ typedef struct vrt_scene_desc {
     uint32_t n_lights;
     const vrt_light* lights;      /* at most VRT_MAX_LIGHTS */
     vrt_shading shading;
+    /* Textures (all optional). */
+    uint32_t n_textures;
+    const vrt_texture* textures;
+    const int32_t* material_texture; /* n_materials entries: texture index or -1; NULL = none */
+    const float* uvs;                /* n_vertices * 2 mesh texture coordinates, or NULL for (0,0).
+                                        RaycastHit.textureCoord is (0,0) on sphere and box colliders. */
 } vrt_scene_desc;
 
 #define VRT_MAX_LIGHTS 8

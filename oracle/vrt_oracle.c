@@ -482,6 +482,48 @@ static float fresnel_kr(v3 normal, v3 direction, float eta_in, float eta_out)
     return 0.5f * (rpar * rpar + rper * rper);
 }
 
+/* Texture2D.GetPixel with out-of-range coordinates handled by the wrap mode. */
+static int wrap_pixel(int p, int n, int wrap)
+{
+    if (wrap == 1) return p < 0 ? 0 : (p >= n ? n - 1 : p);
+    p %= n;
+    return p < 0 ? p + n : p;
+}
+
+/* Tracer/WhittedTracer.cs:55-63: the texel under hit.textureCoord.  textureCoord is (0,0) on
+ * sphere and box colliders; on a mesh it is the barycentric mix of the vertex coordinates, the
+ * barycentrics being those of the triangle test (u/det, v/det). */
+static col texel_at_hit(const vrt_scene_desc* d, const vrt_texture* tx, ohit hit, oray ray)
+{
+    float tu = 0.f, tv = 0.f;
+    uint32_t first_tri = d->n_spheres + d->n_boxes;
+    if ((uint32_t)hit.prim >= first_tri && d->uvs) {
+        uint32_t ti = (uint32_t)hit.prim - first_tri;
+        v3 v0, v1, v2;
+        tri_verts(d, ti, &v0, &v1, &v2);
+        v3 e1 = vsub(v1, v0), e2 = vsub(v2, v0);
+        v3 pvec = vcross(ray.d, e2);
+        float det = vdot(e1, pvec);
+        v3 tvec = vsub(ray.o, v0);
+        float u = vdot(tvec, pvec);
+        v3 qvec = vcross(tvec, e1);
+        float v = vdot(ray.d, qvec);
+        float bu = u / det, bv = v / det;
+        float bw = 1.f - bu - bv;
+        const uint32_t* ix = d->indices + 3 * (size_t)ti;
+        const float* a = d->uvs + 2 * (size_t)ix[0];
+        const float* b = d->uvs + 2 * (size_t)ix[1];
+        const float* cc = d->uvs + 2 * (size_t)ix[2];
+        tu = a[0] * bw + b[0] * bu + cc[0] * bv;
+        tv = a[1] * bw + b[1] * bu + cc[1] * bv;
+    }
+    float px = tu * (float)tx->width, py = tv * (float)tx->height; /* :59-61 */
+    int ix_ = wrap_pixel((int)floorf(px), tx->width, tx->wrap);
+    int iy_ = wrap_pixel((int)floorf(py), tx->height, tx->wrap);
+    const float* t = tx->rgba + 4 * ((size_t)iy_ * tx->width + ix_);
+    return C(t[0], t[1], t[2], t[3]);
+}
+
 static col shade(octx* c, ohit hit, oray ray, int depth)
 {
     const vrt_scene_desc* d = c->scene->d;
@@ -491,6 +533,9 @@ static col shade(octx* c, ohit hit, oray ray, int depth)
     else if ((uint32_t)hit.prim - d->n_spheres < d->n_boxes) mi = d->boxes[hit.prim - d->n_spheres].material;
     else mi = d->tri_material ? d->tri_material[hit.prim - d->n_spheres - d->n_boxes] : 0;
     const vrt_material* m = &d->materials[mi];
+    if (d->material_texture && d->n_textures && d->material_texture[mi] >= 0 &&
+        (uint32_t)d->material_texture[mi] < d->n_textures)
+        return texel_at_hit(d, &d->textures[d->material_texture[mi]], hit, ray);
     col cd = C(m->color[0], m->color[1], m->color[2], m->color[3]);
     v3 n = hit.normal;
 

@@ -5,7 +5,7 @@ test-side oracle binding can share the data formats.
 """
 import ctypes as C
 
-VRT_ABI_VERSION = 2
+VRT_ABI_VERSION = 3
 
 VRT_OK = 0
 VRT_ERR_INVALID = -1
@@ -60,6 +60,11 @@ class vrt_shading(C.Structure):
                 ("ao_color", C.c_float * 4)]
 
 
+class vrt_texture(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("wrap", C.c_int32),
+                ("rgba", C.POINTER(C.c_float))]
+
+
 class vrt_scene_desc(C.Structure):
     _fields_ = [("n_spheres", C.c_uint32), ("spheres", C.POINTER(vrt_sphere)),
                 ("n_boxes", C.c_uint32), ("boxes", C.POINTER(vrt_box)),
@@ -68,7 +73,9 @@ class vrt_scene_desc(C.Structure):
                 ("tri_material", C.POINTER(C.c_int32)),
                 ("n_materials", C.c_uint32), ("materials", C.POINTER(vrt_material)),
                 ("n_lights", C.c_uint32), ("lights", C.POINTER(vrt_light)),
-                ("shading", vrt_shading)]
+                ("shading", vrt_shading),
+                ("n_textures", C.c_uint32), ("textures", C.POINTER(vrt_texture)),
+                ("material_texture", C.POINTER(C.c_int32)), ("uvs", C.POINTER(C.c_float))]
 
 
 class vrt_camera(C.Structure):

@@ -25,7 +25,8 @@ struct vrt_ctx {
     float4 *d_sph = nullptr, *d_box = nullptr, *d_tri = nullptr, *d_mat = nullptr, *d_bvh = nullptr, *d_bvh4 = nullptr;
     int* d_prim_mat = nullptr;
     DevLight* d_lights = nullptr;
-    float4 *d_aab = nullptr, *d_cam_pre = nullptr;
+    float4 *d_aab = nullptr, *d_cam_pre = nullptr, *d_tex_data = nullptr;
+    int* d_mat_tex = nullptr; int4* d_tex_info = nullptr; float2* d_tri_uv = nullptr;
     std::vector<float4> h_sph, h_box; // host copies for the camera-origin terms
     DevScene scene;
     bool have_scene = false, use_bvh = false;
@@ -115,8 +116,10 @@ static void free_scene(vrt_ctx* c)
 {
     hipFree(c->d_sph); hipFree(c->d_box); hipFree(c->d_tri); hipFree(c->d_mat); hipFree(c->d_bvh);
     hipFree(c->d_bvh4); hipFree(c->d_prim_mat); hipFree(c->d_lights);
-    hipFree(c->d_aab); hipFree(c->d_cam_pre);
-    c->d_aab = c->d_cam_pre = nullptr;
+    hipFree(c->d_aab); hipFree(c->d_cam_pre); hipFree(c->d_tex_data); hipFree(c->d_mat_tex);
+    hipFree(c->d_tex_info); hipFree(c->d_tri_uv);
+    c->d_aab = c->d_cam_pre = c->d_tex_data = nullptr;
+    c->d_mat_tex = nullptr; c->d_tex_info = nullptr; c->d_tri_uv = nullptr;
     c->d_lights = nullptr;
     c->d_sph = c->d_box = c->d_tri = c->d_mat = c->d_bvh = c->d_bvh4 = nullptr;
     c->d_prim_mat = nullptr;
@@ -261,6 +264,43 @@ extern "C" int vrt_set_scene(vrt_ctx* c, const vrt_scene_desc* d)
         pm[d->n_spheres + d->n_boxes + i] = m;
     }
 
+    // textures (Tracer/WhittedTracer.cs:55-63)
+    std::vector<int> mat_tex;
+    std::vector<int4> tex_info;
+    std::vector<float4> tex_data;
+    std::vector<float2> tri_uv;
+    if (d->n_textures && d->material_texture) {
+        if (!d->textures) return fail(c, VRT_ERR_INVALID, "texture array missing");
+        for (uint32_t i = 0; i < d->n_textures; ++i) {
+            const vrt_texture& t = d->textures[i];
+            if (t.width <= 0 || t.height <= 0 || !t.rgba || (t.wrap != 0 && t.wrap != 1) ||
+                (uint64_t)t.width * t.height + tex_data.size() > 0x7fffffffull)
+                return fail(c, VRT_ERR_INVALID, "bad texture");
+            int4 info; info.x = (int)tex_data.size(); info.y = t.width; info.z = t.height; info.w = t.wrap;
+            tex_info.push_back(info);
+            size_t n = (size_t)t.width * t.height;
+            for (size_t k = 0; k < n; ++k)
+                tex_data.push_back(make_float4(t.rgba[4 * k], t.rgba[4 * k + 1], t.rgba[4 * k + 2], t.rgba[4 * k + 3]));
+        }
+        bool any = false;
+        mat_tex.resize(d->n_materials);
+        for (uint32_t i = 0; i < d->n_materials; ++i) {
+            int tx = d->material_texture[i];
+            if (tx >= (int)d->n_textures) return fail(c, VRT_ERR_INVALID, "material texture out of range");
+            mat_tex[i] = tx < 0 ? -1 : tx;
+            any = any || tx >= 0;
+        }
+        if (!any) mat_tex.clear();
+        if (any && d->uvs && d->n_triangles) {
+            tri_uv.resize(3 * (size_t)d->n_triangles);
+            for (uint32_t i = 0; i < d->n_triangles; ++i)
+                for (int k = 0; k < 3; ++k) {
+                    const float* uv = d->uvs + 2 * (size_t)d->indices[3 * (size_t)i + k];
+                    tri_uv[3 * (size_t)i + k] = make_float2(uv[0], uv[1]);
+                }
+        }
+    }
+
     free_scene(c);
     HIPCHK(c, upload(&c->d_sph, sph));
     HIPCHK(c, upload(&c->d_box, box));
@@ -273,6 +313,13 @@ extern "C" int vrt_set_scene(vrt_ctx* c, const vrt_scene_desc* d)
     S.n_sph = (int)d->n_spheres; S.n_box = (int)d->n_boxes; S.n_tri = (int)d->n_triangles;
     S.n_prims = (int)n_prims;
     S.sph = c->d_sph; S.box = c->d_box; S.tri = c->d_tri; S.prim_mat = c->d_prim_mat; S.mat = c->d_mat;
+    if (!mat_tex.empty()) {
+        HIPCHK(c, upload(&c->d_mat_tex, mat_tex));
+        HIPCHK(c, upload(&c->d_tex_info, tex_info));
+        HIPCHK(c, upload(&c->d_tex_data, tex_data));
+        HIPCHK(c, upload(&c->d_tri_uv, tri_uv));
+        S.mat_tex = c->d_mat_tex; S.tex_info = c->d_tex_info; S.tex_data = c->d_tex_data; S.tri_uv = c->d_tri_uv;
+    }
     S.n_lights = (int)d->n_lights;
     std::vector<DevLight> lights(d->n_lights ? d->n_lights : 1);
     memset(lights.data(), 0, lights.size() * sizeof(DevLight));

@@ -6,6 +6,7 @@
 //   tri   float4[3*n_tri]      (v0.xyz, 0) (e1.xyz, 0) (e2.xyz, 0), e1 = v1-v0, e2 = v2-v0
 //   prim_mat int[n_prims]      material index per primitive id (spheres, boxes, triangles)
 //   mat   float4[n_mat]        (r, g, b, type-as-int-bits)
+//   mat_tex, tex_info, tex_data, tri_uv   textured materials, see DevScene
 //   bvh   float4[4*(n_prims-1)] binary LBVH, one 64-byte node per internal node holding the
 //                              boxes of both children:
 //                              (lo0.xyz, hi0.x) (hi0.yz, lo1.xy) (lo1.z, hi1.xyz) (c0, c1, -, -)
@@ -44,6 +45,11 @@ struct DevScene {
     const float4* aab;     // 2 per box when all_aab: (centre.xyz, face/flip code) (world half extents, r^2)
     int all_aab;           // every box has signed world axes as its axes
     const float4* cam_pre; // per sphere (o-c, |o-c|^2 - r^2), per box (o-c, 0) for o = camera origin
+    // textures (null mat_tex = the scene has none)
+    const int* mat_tex;      // per material: texture index or -1
+    const int4* tex_info;    // per texture: (first texel in tex_data, width, height, wrap)
+    const float4* tex_data;  // texels of all textures, row 0 first
+    const float2* tri_uv;    // 3 per triangle (vertex order of the index list) or null
     int n_lights;
     const DevLight* lights; // n_lights entries in device memory
     // Primitives whose box spans a large part of the scene (a ground box under 10k spheres) would

@@ -663,6 +663,45 @@ __device__ __forceinline__ float fresnel_kr(f3 normal, f3 direction, float eta_i
     return 0.5f * (rpar * rpar + rper * rper);
 }
 
+// Texture2D.GetPixel with out-of-range coordinates handled by the wrap mode (0 repeat, 1 clamp).
+__device__ __forceinline__ int wrap_pixel(int p, int n, int wrap)
+{
+    if (wrap == 1) return p < 0 ? 0 : (p >= n ? n - 1 : p);
+    p %= n;
+    return p < 0 ? p + n : p;
+}
+
+// Tracer/WhittedTracer.cs:55-63: the texel under hit.textureCoord, which is (0,0) on sphere and
+// box colliders and the barycentric mix of the vertex coordinates on a mesh; the barycentrics
+// are those of the triangle test (u/det, v/det), recomputed with the same operations.
+__device__ __forceinline__ f3 texel_at_hit(const DevScene& S, int tx, Hit h, f3 o, f3 d)
+{
+    float tu = 0.f, tv = 0.f;
+    const int first_tri = S.n_sph + S.n_box;
+    if (h.prim >= first_tri && S.tri_uv) {
+        const size_t ti = (size_t)(h.prim - first_tri);
+        const float4* tr = S.tri + 3 * ti;
+        f3 v0 = xyz(tr[0]), e1 = xyz(tr[1]), e2 = xyz(tr[2]);
+        f3 pvec = cross3(d, e2);
+        float det = dot3(e1, pvec);
+        f3 tvec = o - v0;
+        float u = dot3(tvec, pvec);
+        f3 qvec = cross3(tvec, e1);
+        float v = dot3(d, qvec);
+        float bu = u / det, bv = v / det;
+        float bw = 1.f - bu - bv;
+        float2 a = S.tri_uv[3 * ti], b = S.tri_uv[3 * ti + 1], c = S.tri_uv[3 * ti + 2];
+        tu = a.x * bw + b.x * bu + c.x * bv;
+        tv = a.y * bw + b.y * bu + c.y * bv;
+    }
+    const int4 info = S.tex_info[tx];
+    float px = tu * (float)info.y, py = tv * (float)info.z;
+    int ix = wrap_pixel((int)floorf(px), info.y, info.w);
+    int iy = wrap_pixel((int)floorf(py), info.z, info.w);
+    float4 t = S.tex_data[(size_t)info.x + (size_t)iy * info.y + ix];
+    return mk3(t.x, t.y, t.z);
+}
+
 // One surface interaction: direct lighting A and up to two child rays with their weights.
 struct Bounce {
     f3 A;         // Phong term of this hit
@@ -681,7 +720,16 @@ __device__ __forceinline__ void shade_hit(const DevScene& S, const DevParams& P,
 {
     f3 point, n;
     hit_geometry(S, h, o, d, point, n);
-    float4 m = S.mat[S.prim_mat[h.prim]];
+    const int mi = S.prim_mat[h.prim];
+    if (S.mat_tex) {   // a textured material returns its texel unshaded and ends the path
+        const int tx = S.mat_tex[mi];
+        if (tx >= 0) {
+            B.prim = h.prim; B.o = point; B.n_child = 0; B.A = texel_at_hit(S, tx, h, o, d);
+            B.d0 = B.w0 = B.d1 = B.w1 = mk3(0.f, 0.f, 0.f);
+            return;
+        }
+    }
+    float4 m = S.mat[mi];
     int mtype = __float_as_int(m.w);
     f3 cd = mk3(m.x, m.y, m.z);
     const vrt_shading& sh = S.sh;
@@ -991,7 +1039,14 @@ __device__ __forceinline__ float4 trace_pixel_sm(const DevScene& S, const DevCam
                 } else {
                     f3 point;
                     hit_geometry(S, h, qo, qd, point, n);
-                    float4 m = S.mat[S.prim_mat[h.prim]];
+                    const int mi = S.prim_mat[h.prim];
+                    const int tx = S.mat_tex ? S.mat_tex[mi] : -1;
+                    if (tx >= 0) {   // Tracer/WhittedTracer.cs:55-63: texel, unshaded, path ends
+                        L = L + T * texel_at_hit(S, tx, h, qo, qd);
+                        st = ST_NEXT;
+                        continue;
+                    }
+                    float4 m = S.mat[mi];
                     mtype = __float_as_int(m.w);
                     cd = mk3(m.x, m.y, m.z);
                     prim = h.prim; rd = qd; qo = point;

@@ -51,11 +51,24 @@ class Scene:
         self.lights = np.zeros(0, _LIGHT_DT)
         self.shading = default_shading()
         self._mat_names = []
+        self.textures = []      # (rgba float32 [H,W,4], wrap)
+        self.mat_texture = []   # per material: texture index or -1
+        self.uvs = None         # per mesh vertex (u, v)
 
     # ---- building
-    def add_material(self, name, mtype, color):
+    def add_texture(self, rgba, wrap=0):
+        """Material.mainTexture as a float RGBA image [H, W, 4], row 0 = Unity's y = 0;
+        wrap 0 = Repeat, 1 = Clamp."""
+        self.textures.append((np.ascontiguousarray(rgba, np.float32), int(wrap)))
+        return len(self.textures) - 1
+
+    def add_material(self, name, mtype, color, texture=-1):
         """`name` plays the role of the Unity material name that DetermineMaterialType
-        (Util/RayTraceUtility.cs:139-152) switches on."""
+        (Util/RayTraceUtility.cs:139-152) switches on; `texture` that of mainTexture
+        (Tracer/WhittedTracer.cs:55-63)."""
+        while len(self.mat_texture) < len(self.materials):
+            self.mat_texture.append(-1)
+        self.mat_texture.append(int(texture))
         m = np.zeros(1, _MAT_DT)
         m["type"] = mtype
         col = tuple(color) + (1.0,) * (4 - len(color))
@@ -91,7 +104,8 @@ class Scene:
         l["location"] = location
         self.lights = np.concatenate([self.lights, l])
 
-    def set_mesh(self, vertices, indices, tri_material=None):
+    def set_mesh(self, vertices, indices, tri_material=None, uvs=None):
+        self.uvs = None if uvs is None else np.ascontiguousarray(uvs, np.float32).reshape(-1, 2)
         self.vertices = np.ascontiguousarray(vertices, np.float32).reshape(-1, 3)
         self.indices = np.ascontiguousarray(indices, np.uint32).reshape(-1, 3)
         self.tri_material = None if tri_material is None else np.ascontiguousarray(
@@ -121,6 +135,20 @@ class Scene:
         d.n_lights = len(self.lights)
         d.lights = self.lights.ctypes.data_as(C.POINTER(abi.vrt_light))
         d.shading = self.shading
+        if self.textures:
+            self._tex_structs = (abi.vrt_texture * len(self.textures))()
+            for k, (img, wrap) in enumerate(self.textures):
+                t = self._tex_structs[k]
+                t.height, t.width, t.wrap = img.shape[0], img.shape[1], wrap
+                t.rgba = img.ctypes.data_as(C.POINTER(C.c_float))
+            d.n_textures = len(self.textures)
+            d.textures = self._tex_structs
+            mt = list(self.mat_texture) + [-1] * (len(self.materials) - len(self.mat_texture))
+            self._mat_tex = np.ascontiguousarray(mt[:len(self.materials)], np.int32)
+            d.material_texture = self._mat_tex.ctypes.data_as(C.POINTER(C.c_int32))
+        if self.uvs is not None:
+            assert len(self.uvs) == len(self.vertices)
+            d.uvs = self.uvs.ctypes.data_as(C.POINTER(C.c_float))
         return d
 
 
