@@ -236,6 +236,43 @@ def teaching_camera(width=200, height=200):
                        (0.0, 1.0, 0.0), width, height)
 
 
+# --------------------------------------------------------------------------- textured quad
+
+def checker_texture(w, h, a=(1.0, 0.0, 0.0, 1.0), b=(0.0, 0.0, 1.0, 1.0)):
+    """w x h checkerboard; texel (0,0) — the one untextured-coordinate colliders see — is
+    (0.25, 0.5, 0.75)."""
+    img = np.zeros((h, w, 4), np.float32)
+    yy, xx = np.mgrid[0:h, 0:w]
+    img[(xx + yy) % 2 == 0] = a
+    img[(xx + yy) % 2 == 1] = b
+    img[0, 0] = (0.25, 0.5, 0.75, 1.0)
+    return img
+
+
+def textured_quad_scene(wrap=0, uv_scale=1.0):
+    """A textured quad (two triangles) facing -z behind a metal sphere, a textured sphere and a
+    solid floor box, one point light: exercises Tracer/WhittedTracer.cs:55-63 directly and in
+    reflections.  uv_scale > 1 pushes the texture coordinates outside [0, 1]."""
+    s = Scene()
+    tex = s.add_texture(checker_texture(8, 4), wrap)
+    quad = s.add_material("Poster", abi.VRT_MAT_SOLID, (1, 1, 1), texture=tex)
+    metal = s.add_material("Metal", abi.VRT_MAT_METAL, (0.9, 0.9, 0.9))
+    floor = s.add_material("Wood", abi.VRT_MAT_SOLID, (0.8, 0.6, 0.3))
+    ball = s.add_material("Ball", abi.VRT_MAT_SOLID, (1, 1, 1), texture=tex)
+    v = np.array([(-3, 0, 3), (3, 0, 3), (3, 4, 3), (-3, 4, 3)], np.float32)
+    uv = np.array([(0, 0), (1, 0), (1, 1), (0, 1)], np.float32) * uv_scale - (uv_scale - 1) / 2
+    s.set_mesh(v, np.array([(0, 2, 1), (0, 3, 2)], np.uint32), np.array([quad, quad], np.int32), uvs=uv)
+    s.add_sphere((0.0, 1.0, 0.0), 1.0, metal)
+    s.add_sphere((2.2, 0.5, 0.5), 0.5, ball)
+    s.add_box((0, -0.5, 0), (6, 0.5, 6), floor)
+    s.add_light(abi.VRT_LIGHT_POINT, (2, 6, -4), ls=1.0, cast_shadows=True)
+    return s
+
+
+def textured_quad_camera(w=96, h=64):
+    return make_camera((0, 2, -7), (-3, 0, -4), (6, 0, 0), (0, 4, 0), w, h)
+
+
 # --------------------------------------------------------------------------- 10k spheres
 
 def random_spheres_scene(n=10000, seed=0xC0FFEE):

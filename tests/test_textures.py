@@ -10,35 +10,9 @@ from raytracing_amd import abi
 TOL = 1.0 / 255.0
 
 
-def _checker(w, h, a=(1.0, 0.0, 0.0, 1.0), b=(0.0, 0.0, 1.0, 1.0)):
-    img = np.zeros((h, w, 4), np.float32)
-    yy, xx = np.mgrid[0:h, 0:w]
-    img[(xx + yy) % 2 == 0] = a
-    img[(xx + yy) % 2 == 1] = b
-    img[0, 0] = (0.25, 0.5, 0.75, 1.0)  # the texel untextured colliders see
-    return img
-
-
-def _quad_scene(wrap=0, uv_scale=1.0):
-    """A textured quad (two triangles) facing -z behind a metal sphere on a solid floor."""
-    s = ra.Scene()
-    tex = s.add_texture(_checker(8, 4), wrap)
-    quad = s.add_material("Poster", abi.VRT_MAT_SOLID, (1, 1, 1), texture=tex)
-    metal = s.add_material("Metal", abi.VRT_MAT_METAL, (0.9, 0.9, 0.9))
-    floor = s.add_material("Wood", abi.VRT_MAT_SOLID, (0.8, 0.6, 0.3))
-    ball = s.add_material("Ball", abi.VRT_MAT_SOLID, (1, 1, 1), texture=tex)
-    v = np.array([(-3, 0, 3), (3, 0, 3), (3, 4, 3), (-3, 4, 3)], np.float32)
-    uv = np.array([(0, 0), (1, 0), (1, 1), (0, 1)], np.float32) * uv_scale - (uv_scale - 1) / 2
-    s.set_mesh(v, np.array([(0, 2, 1), (0, 3, 2)], np.uint32), np.array([quad, quad], np.int32), uvs=uv)
-    s.add_sphere((0.0, 1.0, 0.0), 1.0, metal)
-    s.add_sphere((2.2, 0.5, 0.5), 0.5, ball)
-    s.add_box((0, -0.5, 0), (6, 0.5, 6), floor)
-    s.add_light(abi.VRT_LIGHT_POINT, (2, 6, -4), ls=1.0, cast_shadows=True)
-    return s
-
-
-def _cam(w=96, h=64):
-    return ra.make_camera((0, 2, -7), (-3, 0, -4), (6, 0, 0), (0, 4, 0), w, h)
+_checker = ra.checker_texture
+_quad_scene = ra.textured_quad_scene
+_cam = ra.textured_quad_camera
 
 
 def test_oracle_texel_lookup(oracle_mod):

@@ -34,6 +34,16 @@ def cases():
     out["c4_mesh48_160x90_1spp_d5"] = (
         ra.tessellated_mesh_scene(quads=48, seed=1), ra.tessellated_mesh_camera(160, 90),
         ra.Params(spp=1, max_depth=5, rng=100.0))
+    jit = oracle.sampler_table(abi.VRT_SAMPLER_JITTERED, 16, 7, 2.4 * (16 / 9) / 96, 2.4 / 54, 3)
+    out["c3_spheres1000_96x54_jittered16_d8"] = (
+        ra.random_spheres_scene(n=1000, seed=8), ra.random_spheres_camera(96, 54),
+        ra.Params(spp=16, offsets=jit, seed=2, max_depth=8, rng=200.0))
+    out["textured_quad_96x64_2spp_d4_repeat3"] = (
+        ra.textured_quad_scene(0, 3.0), ra.textured_quad_camera(96, 64), ra.Params(spp=2, max_depth=4))
+    out["teaching_160x90_fixes_d6"] = (
+        ra.teaching_scene(), ra.teaching_camera(160, 90),
+        ra.Params(spp=1, max_depth=6,
+                  flags=abi.VRT_FIX_DIELECTRIC | abi.VRT_FIX_PRIMARY_SKY | abi.VRT_FIX_AO_BASIS))
     return out
 
 
@@ -42,6 +52,8 @@ def main():
     gdir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(gdir, exist_ok=True)
     for name, (scene, cam, prm) in cases().items():
+        if os.path.exists(os.path.join(gdir, name + ".npz")) and "--all" not in sys.argv:
+            continue  # committed fixtures are only rewritten on request
         rgba, hit, rays = oracle.render(scene, cam, prm.c, n_threads=8)
         assert hit.max() < 32767
         np.savez_compressed(os.path.join(gdir, name + ".npz"), hit=hit.astype(np.int16),
