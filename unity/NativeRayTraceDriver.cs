@@ -1,0 +1,106 @@
+// Frame driver that replaces the per-pixel coroutine of RayTracerUnity
+// (RayTracerUnity.cs:312-352,565-597,607-666) by libvrt: the whole frame is traced on the GPU
+// without blocking Unity's own frame loop, the single-step mode traces one pixel and feeds the
+// ray polyline.  Attach next to RayTracerUnity and hand it the same inspector values; the VR UI
+// keeps talking to RayTracerUnity (play / pause / reset), which forwards to StartFrame / Step.
+using System;
+using System.Collections.Generic;
+using System.Runtime.InteropServices;
+using UnityEngine;
+
+public sealed class NativeRayTraceDriver : MonoBehaviour
+{
+    public float RayTraceRange = 30f;                                   // RayTrace_Range
+    public int SampleSize = 50;                                          // SCN inspector values
+    public AASamplingStrategy SamplingMethod = AASamplingStrategy.Hammersley;
+    public int SampleSetCount = 83;
+    public uint Seed = 1;
+
+    IntPtr _ctx = IntPtr.Zero;
+    VrtNative.Params _prm;
+    float[] _offsets; GCHandle _offsetsPin, _pixelsPin, _idsPin;
+    int[] _hitIds;
+    bool _frameInFlight;
+    VrtSceneMarshaller _scene;
+    public NativeTracer Tracer { get; private set; }
+
+    /// Camera and buffers come from the objects RayTracerUnity.Start builds (:266-307).
+    public void Init(Vector3 rayOrigin, ViewPortPlaneInformation viewPort, TextureInformation texture)
+    {
+        VrtNative.Check(IntPtr.Zero == _ctx ? IntPtr.Zero : _ctx, VrtNative.vrt_abi_version() == VrtNative.AbiVersion ? 0 : -1, "ABI version");
+        VrtNative.Check(IntPtr.Zero, VrtNative.vrt_create(0, out _ctx), "vrt_create");
+        RebuildScene();
+        int dim = texture.TextureDimension;
+        var cam = new VrtNative.Camera { origin = rayOrigin, p0 = viewPort.PlaneBorderPoints[0], xAxis = viewPort.PlaneXAxis,
+                                         yAxis = viewPort.PlaneYAxis, width = dim, height = dim };
+        VrtNative.Check(_ctx, VrtNative.vrt_set_camera(_ctx, ref cam), "vrt_set_camera");
+        // AntiAliasingStrategy constructor (AntiAliasingStrategy.cs:32-67)
+        _offsets = new float[SampleSetCount * SampleSize * 2];
+        VrtNative.Check(_ctx, VrtNative.vrt_sampler_table((int)SamplingMethod, SampleSize, SampleSetCount,
+                                                        viewPort.HorizontalIterationStep, viewPort.VerticalIterationStep, Seed, _offsets), "vrt_sampler_table");
+        _offsetsPin = GCHandle.Alloc(_offsets, GCHandleType.Pinned);
+        VrtNative.vrt_params_defaults(out _prm);
+        _prm.spp = SampleSize; _prm.nSets = SampleSetCount; _prm.offsets = _offsetsPin.AddrOfPinnedObject(); _prm.seed = Seed;
+        _prm.maxDepth = RayTraceUtility.GlobalWorld.MaxDepth; _prm.range = RayTraceRange;
+        _hitIds = new int[dim * dim];
+        _pixelsPin = GCHandle.Alloc(texture.PixelColorData, GCHandleType.Pinned);
+        _idsPin = GCHandle.Alloc(_hitIds, GCHandleType.Pinned);
+        Tracer = new NativeTracer(_ctx, _prm);
+        RayTraceUtility.GlobalWorld.Tracer = Tracer;                      // replaces :300-304
+    }
+
+    /// After scene edits (spawned spheres, material changes) and ResetRaytracer (:450-456).
+    public void RebuildScene()
+    {
+        _scene = new VrtSceneMarshaller();
+        _scene.Collect(RayTraceUtility.LayerMask);
+        _scene.Upload(_ctx);
+    }
+
+    /// Continuous mode: starts the frame; Update polls it.
+    public void StartFrame()
+    {
+        if (_frameInFlight) return;
+        VrtNative.Check(_ctx, VrtNative.vrt_render_begin(_ctx, ref _prm, _pixelsPin.AddrOfPinnedObject(), _idsPin.AddrOfPinnedObject()), "vrt_render_begin");
+        _frameInFlight = true;
+    }
+
+    /// True once PixelColorData holds the frame; the caller then runs UpdateRenderTexture (:461-477).
+    public bool PollFrame()
+    {
+        if (!_frameInFlight) return false;
+        VrtNative.Check(_ctx, VrtNative.vrt_render_poll(_ctx, out int done), "vrt_render_poll");
+        if (done == 0) return false;
+        VrtNative.Check(_ctx, VrtNative.vrt_render_end(_ctx, out VrtNative.Stats _), "vrt_render_end");
+        _frameInFlight = false;
+        return true;
+    }
+
+    /// Single-step mode (RT_IterationMode.Single, :348): one pixel with its ray tree.  Returns the
+    /// pixel colour for SetTexturePixel (:435-444) and fills RT_rec_points (:620-654) with the
+    /// primary / reflection / transmission chain of sample 0.
+    public Color Step(int hCord, int vCord, List<VrtNative.PathSeg> allSegments = null)
+    {
+        var segs = new VrtNative.PathSeg[253];                            // byte counter at :649
+        VrtNative.Check(_ctx, VrtNative.vrt_trace_pixel(_ctx, ref _prm, hCord, vCord, -1, segs, segs.Length, out int n, out Color c, out int _),
+                        "vrt_trace_pixel");
+        RayTraceUtility.RT_rec_points.Clear();
+        for (int i = 0; i < Math.Min(n, segs.Length); ++i)
+        {
+            if (allSegments != null) allSegments.Add(segs[i]);
+            bool chain = segs[i].kind == VrtNative.RayPrimary || segs[i].kind == VrtNative.RayReflect || segs[i].kind == VrtNative.RayTransmit;
+            if (segs[i].sample == 0 && chain && segs[i].depth > 0) RayTraceUtility.RT_rec_points.Add(segs[i].end);
+        }
+        return c;
+    }
+
+    void OnDestroy()
+    {
+        if (_ctx == IntPtr.Zero) return;
+        if (_frameInFlight) VrtNative.vrt_render_end(_ctx, out VrtNative.Stats _);
+        VrtNative.vrt_destroy(_ctx); _ctx = IntPtr.Zero;
+        if (_offsetsPin.IsAllocated) _offsetsPin.Free();
+        if (_pixelsPin.IsAllocated) _pixelsPin.Free();
+        if (_idsPin.IsAllocated) _idsPin.Free();
+    }
+}
