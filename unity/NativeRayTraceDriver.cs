@@ -27,7 +27,7 @@ public sealed class NativeRayTraceDriver : MonoBehaviour
     /// Camera and buffers come from the objects RayTracerUnity.Start builds (:266-307).
     public void Init(Vector3 rayOrigin, ViewPortPlaneInformation viewPort, TextureInformation texture)
     {
-        VrtNative.Check(IntPtr.Zero == _ctx ? IntPtr.Zero : _ctx, VrtNative.vrt_abi_version() == VrtNative.AbiVersion ? 0 : -1, "ABI version");
+        if (VrtNative.vrt_abi_version() != VrtNative.AbiVersion) throw new InvalidOperationException("libvrt: ABI version mismatch");
         VrtNative.Check(IntPtr.Zero, VrtNative.vrt_create(0, out _ctx), "vrt_create");
         RebuildScene();
         int dim = texture.TextureDimension;
