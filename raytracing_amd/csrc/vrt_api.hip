@@ -529,12 +529,16 @@ static int enqueue_frame(vrt_ctx* c, const vrt_params* p, const DevParams& P, fl
         size_t per_row = (size_t)c->cam.width * P.spp;
         size_t want = per_row * (size_t)(P.local_rows > 0 ? P.local_rows : 1);
         size_t min_band = per_row * 8;
-        if (want > kWfMaxSlots) want = kWfMaxSlots > min_band ? kWfMaxSlots : min_band;
+        size_t max_slots = kWfMaxSlots;
+        if (const char* e = getenv("VRT_WF_MAX_SLOTS")) { long long v = atoll(e); if (v > 0) max_slots = (size_t)v; } // tests: force bands
+        if (want > max_slots) want = max_slots > min_band ? max_slots : min_band;
         if (want < min_band) want = min_band;
         if (want * (two ? 2 : 1) > 0x7fffffffull) return fail(c, VRT_ERR_CAPACITY, "frame row too long for the wavefront queues");
         int rc = ensure_wf(c, want, two);
         if (rc) return rc;
-        HIPCHK(c, vrt_launch_wavefront(c->scene, c->cam, P, c->use_bvh, two, c->wf, rgba, hit, c->d_ctr, stream));
+        WfWorkspace wf = c->wf;
+        wf.slots = want; // a workspace kept from a larger frame still runs this frame in bands of `want`
+        HIPCHK(c, vrt_launch_wavefront(c->scene, c->cam, P, c->use_bvh, two, wf, rgba, hit, c->d_ctr, stream));
     } else {
         HIPCHK(c, vrt_launch_mega(c->scene, c->cam, P, c->use_bvh, two, rgba, hit, c->d_ctr, stream));
     }

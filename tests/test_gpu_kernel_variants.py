@@ -109,3 +109,35 @@ def test_rays_along_box_edges_and_axes(vrt_ctx, oracle_mod):
     _check(vrt_ctx, oracle_mod, s, cam, ra.Params(spp=1, max_depth=3))
     cam2 = ra.make_camera((1, 1, -5), (-3, -3, -1), (8, 0, 0), (0, 8, 0), 64, 64)
     _check(vrt_ctx, oracle_mod, s, cam2, ra.Params(spp=1, max_depth=3))
+
+
+@pytest.mark.parametrize("spp", [1, 5, 16])
+def test_wavefront_bands_equal_megakernel(vrt_ctx, spp):
+    """The wavefront pipeline works through the frame in bands of rows that fit its sample-slot
+    budget; with the budget forced down to a few rows the frame must still be the megakernel's
+    bit for bit, strips and ragged last bands included."""
+    scene, cam = ra.random_spheres_scene(300), ra.random_spheres_camera(75, 53)
+    offs = host.sampler_table(abi.VRT_SAMPLER_RANDOM, spp, 5, 0.02, 0.02, seed=11)
+    kw = dict(spp=spp, offsets=offs, seed=5, max_depth=6, rng=200.0)
+    vrt_ctx.set_scene(scene)
+    vrt_ctx.set_camera(cam)
+    ref, ref_hit, ref_st = vrt_ctx.render(ra.Params(mode=abi.VRT_MODE_MEGAKERNEL, **kw))
+    old = os.environ.get("VRT_WF_MAX_SLOTS")
+    try:
+        for budget in (75 * spp * 8, 75 * spp * 19, 10 ** 9):
+            os.environ["VRT_WF_MAX_SLOTS"] = str(budget)
+            got, got_hit, st = vrt_ctx.render(ra.Params(mode=abi.VRT_MODE_WAVEFRONT, **kw))
+            assert st.mode_used == abi.VRT_MODE_WAVEFRONT
+            assert np.array_equal(got, ref, equal_nan=True) and np.array_equal(got_hit, ref_hit)
+            assert list(st.rays) == list(ref_st.rays)
+        os.environ["VRT_WF_MAX_SLOTS"] = str(75 * spp * 8)
+        rows = [h for h in range(53) if (h // 8) % 3 == 1]
+        out = np.zeros((len(rows), 75, 4), np.float32)
+        vrt_ctx.render(ra.Params(mode=abi.VRT_MODE_WAVEFRONT, tile_index=1, tile_count=3, tile_rows=8,
+                                 compact_rows=True, **kw), rgba=out, hit=np.zeros((len(rows), 75), np.int32))
+        assert np.array_equal(out, ref[rows], equal_nan=True)
+    finally:
+        if old is None:
+            os.environ.pop("VRT_WF_MAX_SLOTS", None)
+        else:
+            os.environ["VRT_WF_MAX_SLOTS"] = old
