@@ -395,6 +395,8 @@ def main():
             "ms_per_frame_kernel": kernel_ms,
             "roofline": roof,
         }
+        if st.bvh_nodes:
+            out["config"]["bvh_build_ms"] = st.bvh_build_ms
         if st.nodes_visited:  # only a library built with -DVRT_COUNT_NODES=1 counts these
             out["traversal"] = {"nodes_per_ray": st.nodes_visited / max(my_queries, 1),
                                 "prims_per_ray": st.prims_tested / max(my_queries, 1)}

@@ -266,6 +266,100 @@ __global__ __launch_bounds__(256) void k_collapse4(int n_inner, const float4* __
     w[7] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
+// ------------------------------------------------------------------ PLOC
+// Parallel locally-ordered clustering (Meister & Bittner 2017) on the Morton-sorted primitives:
+// every round each cluster looks at its VRT_PLOC_RADIUS neighbours on either side for the one
+// whose union box has the smallest surface area; clusters that chose each other merge into a new
+// inner node, the rest carry over, and the survivors are compacted in order.  The result is a
+// binary tree in the same node layout as the LBVH's, usually with less overlap.  Node ids are
+// handed out downwards so that the last merge, the root, is node 0.
+#ifndef VRT_PLOC_RADIUS
+#define VRT_PLOC_RADIUS 12
+#endif
+
+__global__ __launch_bounds__(256) void k_ploc_init(int n, const unsigned* __restrict__ vals, const float4* __restrict__ pbox,
+                                                   int* __restrict__ code, float4* __restrict__ lo, float4* __restrict__ hi)
+{
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int prim = (int)vals[i];
+    code[i] = ~prim;
+    lo[i] = pbox[2 * (size_t)prim];
+    hi[i] = pbox[2 * (size_t)prim + 1];
+}
+
+__global__ __launch_bounds__(256) void k_ploc_nn(int m, const float4* __restrict__ lo, const float4* __restrict__ hi,
+                                                 int* __restrict__ nn)
+{
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    float4 a = lo[i], b = hi[i];
+    int best = -1;
+    float best_area = INFINITY;
+    int j0 = max(0, i - VRT_PLOC_RADIUS), j1 = min(m - 1, i + VRT_PLOC_RADIUS);
+    for (int j = j0; j <= j1; ++j) {
+        if (j == i) continue;
+        float4 c = lo[j], d = hi[j];
+        float dx = fmaxf(b.x, d.x) - fminf(a.x, c.x);
+        float dy = fmaxf(b.y, d.y) - fminf(a.y, c.y);
+        float dz = fmaxf(b.z, d.z) - fminf(a.z, c.z);
+        float area = dx * dy + dy * dz + dz * dx;
+        if (area < best_area) { best_area = area; best = j; } // ties: the lower index, so a mutual pair always exists
+    }
+    nn[i] = best;
+}
+
+// flags[i] = valid | merge << 32 (summed by one 64-bit scan)
+__global__ __launch_bounds__(256) void k_ploc_flags(int m, const int* __restrict__ nn, unsigned long long* __restrict__ flags)
+{
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    int j = nn[i];
+    bool mutual = j >= 0 && nn[j] == i;
+    unsigned long long f;
+    if (mutual && i < j) f = 1ull | (1ull << 32);
+    else if (mutual) f = 0ull;
+    else f = 1ull;
+    flags[i] = f;
+}
+
+__global__ __launch_bounds__(256) void k_ploc_emit(int m, int left, const int* __restrict__ nn,
+                                                   const unsigned long long* __restrict__ flags,
+                                                   const unsigned long long* __restrict__ scan,
+                                                   const int* __restrict__ code, const float4* __restrict__ lo,
+                                                   const float4* __restrict__ hi, int* __restrict__ code_out,
+                                                   float4* __restrict__ lo_out, float4* __restrict__ hi_out,
+                                                   float4* __restrict__ nodes, int* __restrict__ parent,
+                                                   int* __restrict__ leaf_parent)
+{
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    unsigned long long f = flags[i];
+    if (!(f & 1ull)) return;
+    unsigned long long sc = scan[i];
+    int pos = (int)(unsigned)sc, rank = (int)(unsigned)(sc >> 32);
+    int c = code[i];
+    float4 a = lo[i], b = hi[i];
+    if (f >> 32) {
+        int j = nn[i];
+        int id = left - 1 - rank;
+        int cj = code[j];
+        float4 cl = lo[j], ch = hi[j];
+        float4* nd = nodes + 4 * (size_t)id;
+        nd[0] = make_float4(a.x, a.y, a.z, b.x);
+        nd[1] = make_float4(b.y, b.z, cl.x, cl.y);
+        nd[2] = make_float4(cl.z, ch.x, ch.y, ch.z);
+        nd[3] = make_float4(__int_as_float(c), __int_as_float(cj), 0.f, 0.f);
+        if (c >= 0) parent[c] = id; else leaf_parent[~c] = id;
+        if (cj >= 0) parent[cj] = id; else leaf_parent[~cj] = id;
+        if (id == 0) parent[0] = -1;
+        a = make_float4(fminf(a.x, cl.x), fminf(a.y, cl.y), fminf(a.z, cl.z), 0.f);
+        b = make_float4(fmaxf(b.x, ch.x), fmaxf(b.y, ch.y), fmaxf(b.z, ch.z), 0.f);
+        c = id;
+    }
+    code_out[pos] = c; lo_out[pos] = a; hi_out[pos] = b;
+}
+
 // Surface-area-guided 4-wide collapse, one lane per node of the current wide level: the node
 // starts from its two binary children and, while it has a free slot, opens the inner child with
 // the largest box (Wald et al.'s greedy collapse).  Inner children that are left become the
@@ -345,7 +439,7 @@ hipError_t vrt_build_lbvh(const DevScene& S, float4* nodes, float4* wide, int* d
 
     BCHK(hipEventCreate(&e0)); BCHK(hipEventCreate(&e1));
     BCHK(hipMalloc(&pbox, 2 * (size_t)n * sizeof(float4)));
-    BCHK(hipMalloc(&parked, 4 * (size_t)(n - 1) * sizeof(float4)));
+    BCHK(hipMalloc(&parked, 4 * (size_t)n * sizeof(float4)));
     BCHK(hipMalloc(&cb, 6 * sizeof(unsigned)));
     BCHK(hipMalloc(&keys, (size_t)n * 8)); BCHK(hipMalloc(&keys2, (size_t)n * 8));
     BCHK(hipMalloc(&vals, (size_t)n * 4)); BCHK(hipMalloc(&vals2, (size_t)n * 4));
@@ -364,9 +458,55 @@ hipError_t vrt_build_lbvh(const DevScene& S, float4* nodes, float4* wide, int* d
     hipLaunchKernelGGL(k_prim_bounds, dim3(blocks), dim3(256), 0, stream, S, pbox, cb);
     hipLaunchKernelGGL(k_morton, dim3(blocks), dim3(256), 0, stream, n, pbox, cb, keys, vals);
     BCHK(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys2, vals, vals2, (size_t)n, 0, 63, stream));
-    hipLaunchKernelGGL(k_hierarchy, dim3(blocks), dim3(256), 0, stream, n, keys2, child, parent, leaf_parent);
-    hipLaunchKernelGGL(k_fit, dim3(blocks), dim3(256), 0, stream, n, vals2, pbox, child, parent, leaf_parent, arrived,
-                       parked, nodes);
+    {
+        const char* bsel = getenv("VRT_BUILDER");
+        bool ploc = !(bsel && strcmp(bsel, "lbvh") == 0);
+        if (ploc) {
+            // cluster arrays, ping-pong; `parked` (4 float4 per node) holds the four box arrays
+            int *code_a = nullptr, *code_b = nullptr, *nn = nullptr;
+            unsigned long long *flags = nullptr, *scan = nullptr;
+            void* stmp = nullptr; size_t stmp_bytes = 0;
+            float4 *lo_a = parked, *hi_a = parked + n, *lo_b = parked + 2 * (size_t)n, *hi_b = parked + 3 * (size_t)n;
+            hipError_t pe = hipSuccess;
+#define PCHK(expr) do { pe = (expr); if (pe != hipSuccess) goto ploc_done; } while (0)
+            PCHK(hipMalloc(&code_a, (size_t)n * 4)); PCHK(hipMalloc(&code_b, (size_t)n * 4)); PCHK(hipMalloc(&nn, (size_t)n * 4));
+            PCHK(hipMalloc(&flags, (size_t)n * 8)); PCHK(hipMalloc(&scan, (size_t)n * 8));
+            PCHK(rocprim::exclusive_scan(nullptr, stmp_bytes, flags, scan, 0ull, (size_t)n, rocprim::plus<unsigned long long>(), stream));
+            PCHK(hipMalloc(&stmp, stmp_bytes ? stmp_bytes : 16));
+            hipLaunchKernelGGL(k_ploc_init, dim3(blocks), dim3(256), 0, stream, n, vals2, pbox, code_a, lo_a, hi_a);
+            {
+                int m = n, left = n - 1;
+                while (m > 1) {
+                    int mb = (m + 255) / 256;
+                    hipLaunchKernelGGL(k_ploc_nn, dim3(mb), dim3(256), 0, stream, m, lo_a, hi_a, nn);
+                    hipLaunchKernelGGL(k_ploc_flags, dim3(mb), dim3(256), 0, stream, m, nn, flags);
+                    PCHK(rocprim::exclusive_scan(stmp, stmp_bytes, flags, scan, 0ull, (size_t)m,
+                                                 rocprim::plus<unsigned long long>(), stream));
+                    hipLaunchKernelGGL(k_ploc_emit, dim3(mb), dim3(256), 0, stream, m, left, nn, flags, scan, code_a, lo_a, hi_a,
+                                       code_b, lo_b, hi_b, nodes, parent, leaf_parent);
+                    unsigned long long last_f = 0, last_s = 0;
+                    PCHK(hipMemcpyAsync(&last_f, flags + (m - 1), 8, hipMemcpyDeviceToHost, stream));
+                    PCHK(hipMemcpyAsync(&last_s, scan + (m - 1), 8, hipMemcpyDeviceToHost, stream));
+                    PCHK(hipStreamSynchronize(stream));
+                    unsigned long long tot = last_f + last_s;
+                    int m2 = (int)(unsigned)tot, merges = (int)(unsigned)(tot >> 32);
+                    if (merges <= 0 || m2 != m - merges) { pe = hipErrorUnknown; goto ploc_done; } // cannot happen: a mutual pair always exists
+                    m = m2; left -= merges;
+                    int* tc = code_a; code_a = code_b; code_b = tc;
+                    float4* t4 = lo_a; lo_a = lo_b; lo_b = t4;
+                    t4 = hi_a; hi_a = hi_b; hi_b = t4;
+                }
+            }
+ploc_done:
+#undef PCHK
+            hipFree(code_a); hipFree(code_b); hipFree(nn); hipFree(flags); hipFree(scan); hipFree(stmp);
+            BCHK(pe);
+        } else {
+            hipLaunchKernelGGL(k_hierarchy, dim3(blocks), dim3(256), 0, stream, n, keys2, child, parent, leaf_parent);
+            hipLaunchKernelGGL(k_fit, dim3(blocks), dim3(256), 0, stream, n, vals2, pbox, child, parent, leaf_parent, arrived,
+                               parked, nodes);
+        }
+    }
     hipLaunchKernelGGL(k_depth, dim3(blocks), dim3(256), 0, stream, n, parent, leaf_parent, depth);
     {
         // Greedy collapse level by level (the number of levels bounds the traversal stack: three
