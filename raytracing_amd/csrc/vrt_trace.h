@@ -438,36 +438,39 @@ __device__ __forceinline__ Hit intersect_bvh4(const DevScene& S, f3 o, f3 d, flo
                 VRT_SLAB4(t3, h3, ax23.y, bx23.y, ay23.y, by23.y, az23.y, bz23.y)
 #undef VRT_SLAB4
             }
+#define VRT_PUSH4(T, C)                                                                              \
+            {                                                                                        \
+                unsigned long long e_ = ((unsigned long long)__float_as_uint(T) << 32) | (unsigned)(C); \
+                if (sp < VRT_LDS_STACK4) my_lds[sp * VRT_STACK_LANES] = e_;                          \
+                else if (sp < VRT_BVH4_STACK) deep[sp - VRT_LDS_STACK4] = e_;                        \
+                sp++;                                                                                \
+            }
             // unused slots hold boxes at +inf, which no ray passes
-            t0 = h0 ? t0 : INFINITY;
-            t1 = h1 ? t1 : INFINITY;
-            t2 = h2 ? t2 : INFINITY;
-            t3 = h3 ? t3 : INFINITY;
-            if (!ANY) {
+            if (ANY) {
+                // any-hit: the visiting order is irrelevant; the first hit child is entered, the
+                // others wait with distance 0 (never dropped at pop time)
+                bool taken = false;
+#define VRT_VISIT_ANY(H, C) if (H) { if (!taken) { node = C; taken = true; } else VRT_PUSH4(0.f, C) }
+                VRT_VISIT_ANY(h0, c0) VRT_VISIT_ANY(h1, c1) VRT_VISIT_ANY(h2, c2) VRT_VISIT_ANY(h3, c3)
+#undef VRT_VISIT_ANY
+                pop = !taken;
+            } else {
+                t0 = h0 ? t0 : INFINITY;
+                t1 = h1 ? t1 : INFINITY;
+                t2 = h2 ? t2 : INFINITY;
+                t3 = h3 ? t3 : INFINITY;
                 order2(t0, c0, t1, c1); order2(t2, c2, t3, c3);
                 order2(t0, c0, t2, c2); order2(t1, c1, t3, c3);
                 order2(t1, c1, t2, c2);
-            } else {
-                // any-hit: order is irrelevant, just move the hits to the front
-                if (!(t0 < INFINITY)) { t0 = t1; c0 = c1; t1 = INFINITY; }
-                if (!(t0 < INFINITY)) { t0 = t2; c0 = c2; t2 = INFINITY; }
-                if (!(t0 < INFINITY)) { t0 = t3; c0 = c3; t3 = INFINITY; }
-            }
-            if (t0 < INFINITY) {
-                node = c0;
-                pop = false;
-#define VRT_PUSH4(T, C)                                                                              \
-                if (T < INFINITY) {                                                                  \
-                    unsigned long long e_ = ((unsigned long long)__float_as_uint(T) << 32) | (unsigned)(C); \
-                    if (sp < VRT_LDS_STACK4) my_lds[sp * VRT_STACK_LANES] = e_;                      \
-                    else if (sp < VRT_BVH4_STACK) deep[sp - VRT_LDS_STACK4] = e_;                    \
-                    sp++;                                                                            \
+                if (t0 < INFINITY) {
+                    node = c0;
+                    pop = false;
+                    if (t3 < INFINITY) VRT_PUSH4(t3, c3)
+                    if (t2 < INFINITY) VRT_PUSH4(t2, c2)
+                    if (t1 < INFINITY) VRT_PUSH4(t1, c1)
                 }
-                VRT_PUSH4(t3, c3)
-                VRT_PUSH4(t2, c2)
-                VRT_PUSH4(t1, c1)
-#undef VRT_PUSH4
             }
+#undef VRT_PUSH4
         } else if (leaf_now) {
             int id = ~node;
             count_lanes(S, 7);
