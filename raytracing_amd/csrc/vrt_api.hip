@@ -22,7 +22,7 @@ struct vrt_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_done = nullptr;
     bool pending = false; // a vrt_render_begin frame is in flight
     // scene
-    float4 *d_sph = nullptr, *d_box = nullptr, *d_tri = nullptr, *d_mat = nullptr, *d_bvh = nullptr, *d_bvh4 = nullptr;
+    float4 *d_sph = nullptr, *d_box = nullptr, *d_tri = nullptr, *d_mat = nullptr, *d_bvh = nullptr, *d_bvh4 = nullptr, *d_bvh_top = nullptr;
     int* d_prim_mat = nullptr;
     DevLight* d_lights = nullptr;
     float4 *d_aab = nullptr, *d_cam_pre = nullptr, *d_tex_data = nullptr;
@@ -115,7 +115,7 @@ extern "C" int vrt_create(int device, vrt_ctx** out)
 static void free_scene(vrt_ctx* c)
 {
     hipFree(c->d_sph); hipFree(c->d_box); hipFree(c->d_tri); hipFree(c->d_mat); hipFree(c->d_bvh);
-    hipFree(c->d_bvh4); hipFree(c->d_prim_mat); hipFree(c->d_lights);
+    hipFree(c->d_bvh4); hipFree(c->d_bvh_top); c->d_bvh_top = nullptr; hipFree(c->d_prim_mat); hipFree(c->d_lights);
     hipFree(c->d_aab); hipFree(c->d_cam_pre); hipFree(c->d_tex_data); hipFree(c->d_mat_tex);
     hipFree(c->d_tex_info); hipFree(c->d_tri_uv);
     c->d_aab = c->d_cam_pre = c->d_tex_data = nullptr;
@@ -380,8 +380,9 @@ extern "C" int vrt_set_scene(vrt_ctx* c, const vrt_scene_desc* d)
                 S.big[S.n_big++] = ext[i].second;
         HIPCHK(c, hipMalloc(&c->d_bvh, 4 * (size_t)(n_prims - 1) * sizeof(float4)));
         HIPCHK(c, hipMalloc(&c->d_bvh4, 8 * (size_t)(n_prims - 1) * sizeof(float4)));
-        S.bvh = c->d_bvh; S.bvh4 = c->d_bvh4;
-        hipError_t e = vrt_build_lbvh(S, c->d_bvh, c->d_bvh4, &c->bvh_depth, &c->bvh_ms, c->stream);
+        HIPCHK(c, hipMalloc(&c->d_bvh_top, 8 * VRT_TOP_NODES * sizeof(float4)));
+        S.bvh = c->d_bvh; S.bvh4 = c->d_bvh4; S.bvh_top = c->d_bvh_top;
+        hipError_t e = vrt_build_lbvh(S, c->d_bvh, c->d_bvh4, c->d_bvh_top, &c->bvh_depth, &c->bvh_ms, c->stream);
         if (e != hipSuccess) return fail(c, VRT_ERR_HIP, std::string("LBVH build: ") + hipGetErrorString(e));
         if (c->bvh_depth > VRT_BVH_STACK - 2)
             return fail(c, VRT_ERR_CAPACITY, "LBVH deeper than the traversal stack");

@@ -417,11 +417,33 @@ __global__ __launch_bounds__(256) void k_collapse4_level(const float4* __restric
     w[7] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
+// Copies the first VRT_TOP_NODES wide nodes in breadth-first order into a compact table for LDS
+// staging; child codes that point into the table become VRT_TOP_BASE + table index.  One lane.
+__global__ void k_top_table(const float4* __restrict__ wide, float4* __restrict__ top)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    int ids[VRT_TOP_NODES];
+    int n = 1;
+    ids[0] = 0;
+    for (int k = 0; k < n; ++k) {            // breadth-first: entries are appended while scanning
+        const float4* w = wide + 8 * (size_t)ids[k];
+        float4 c = w[6];
+        int code[4] = {__float_as_int(c.x), __float_as_int(c.y), __float_as_int(c.z), __float_as_int(c.w)};
+        for (int j = 0; j < 4; ++j)
+            if (code[j] >= 0 && code[j] != VRT_BVH4_EMPTY && n < VRT_TOP_NODES) { ids[n] = code[j]; code[j] = VRT_TOP_BASE + n; ++n; }
+        for (int q = 0; q < 8; ++q) top[8 * k + q] = w[q];
+        top[8 * k + 6] = make_float4(__int_as_float(code[0]), __int_as_float(code[1]), __int_as_float(code[2]),
+                                     __int_as_float(code[3]));
+    }
+    for (int k = n; k < VRT_TOP_NODES; ++k)
+        for (int q = 0; q < 8; ++q) top[8 * k + q] = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
+}
+
 } // namespace
 
 #define BCHK(expr) do { e = (expr); if (e != hipSuccess) goto done; } while (0)
 
-hipError_t vrt_build_lbvh(const DevScene& S, float4* nodes, float4* wide, int* depth_out, float* ms_out,
+hipError_t vrt_build_lbvh(const DevScene& S, float4* nodes, float4* wide, float4* top, int* depth_out, float* ms_out,
                           hipStream_t stream)
 {
     const int n = S.n_prims;
@@ -532,6 +554,7 @@ ploc_done:
         }
         if (!greedy)
             hipLaunchKernelGGL(k_collapse4, dim3((n - 1 + 255) / 256), dim3(256), 0, stream, n - 1, nodes, parent, wide);
+        hipLaunchKernelGGL(k_top_table, dim3(1), dim3(64), 0, stream, wide, top);
     }
     BCHK(hipEventRecord(e1, stream));
     BCHK(hipGetLastError());

@@ -41,6 +41,8 @@ struct DevScene {
     const float4* mat;
     const float4* bvh;
     const float4* bvh4;
+    const float4* bvh_top; // VRT_TOP_NODES 4-wide nodes from the top of the tree in breadth-first order;
+                           // children inside the table are coded VRT_TOP_BASE + table index
     // brute-force scenes only:
     const float4* aab;     // 2 per box when all_aab: (centre.xyz, face/flip code) (world half extents, r^2)
     int all_aab;           // every box has signed world axes as its axes
@@ -102,3 +104,5 @@ struct RayQueue {
 #define VRT_BVH_STACK 64
 #define VRT_BVH4_STACK 96
 #define VRT_BVH4_EMPTY ((int)0x80000000)
+#define VRT_TOP_NODES 21
+#define VRT_TOP_BASE 0x40000000

@@ -31,6 +31,6 @@ hipError_t vrt_launch_wavefront(const DevScene& S, const DevCam& cam, const DevP
 
 // LBVH build on the device.  prim arrays are those of DevScene; writes 4*(n_prims-1) float4
 // binary nodes to `nodes` and 8*(n_prims-1) float4 of 4-wide nodes to `wide` (slots of absorbed
-// nodes stay unwritten).  Returns the binary tree depth in *depth_out.  Synchronises the stream.
-hipError_t vrt_build_lbvh(const DevScene& S, float4* nodes, float4* wide, int* depth_out, float* ms_out,
+// nodes stay unwritten) and the 8*VRT_TOP_NODES float4 breadth-first top table to `top`.  Returns the binary tree depth in *depth_out.  Synchronises the stream.
+hipError_t vrt_build_lbvh(const DevScene& S, float4* nodes, float4* wide, float4* top, int* depth_out, float* ms_out,
                           hipStream_t stream);

@@ -353,6 +353,23 @@ __device__ __forceinline__ Hit intersect_bvh(const DevScene& S, f3 o, f3 d, floa
 #define VRT_LEAF_BATCH 0
 #endif
 
+// VRT_LDS_TOP=1 stages the top VRT_TOP_NODES nodes of the 4-wide tree in LDS (whole block calls
+// stage_bvh_top once) and the traversal reads nodes coded >= VRT_TOP_BASE from there.
+#ifndef VRT_LDS_TOP
+#define VRT_LDS_TOP 0
+#endif
+#if VRT_LDS_TOP
+__shared__ float4 g_lds_top[8 * VRT_TOP_NODES];
+__device__ __forceinline__ void stage_bvh_top(const DevScene& S)
+{
+    if (S.bvh_top)
+        for (int k = threadIdx.x; k < 8 * VRT_TOP_NODES; k += blockDim.x) g_lds_top[k] = S.bvh_top[k];
+    __syncthreads();
+}
+#else
+__device__ __forceinline__ void stage_bvh_top(const DevScene&) {}
+#endif
+
 // Orders two (tnear, code) candidates, nearer first.
 __device__ __forceinline__ void order2(float& ta, int& ca, float& tb, int& cb)
 {
@@ -396,7 +413,7 @@ __device__ __forceinline__ Hit intersect_bvh4(const DevScene& S, f3 o, f3 d, flo
     }
     unsigned long long deep[VRT_BVH4_STACK - VRT_LDS_STACK4];
     int sp = 0;
-    int node = 0;
+    int node = VRT_LDS_TOP ? VRT_TOP_BASE : 0;
     bool done = false;
     // every node is entered at most once; the bound only guards against a corrupt tree
     for (int guard = (VRT_LEAF_BATCH ? 64 : 1) * (2 * S.n_prims + 8); guard > 0 && !done; --guard) {
@@ -411,8 +428,17 @@ __device__ __forceinline__ Hit intersect_bvh4(const DevScene& S, f3 o, f3 d, flo
 #endif
         if (node >= 0) {
             count_lanes(S, 6);
-            const float4* n = S.bvh4 + 8 * (size_t)node;
-            const float4 lx = n[0], ly = n[1], lz = n[2], hx = n[3], hy = n[4], hz = n[5], cc = n[6];
+            float4 lx, ly, lz, hx, hy, hz, cc;
+#if VRT_LDS_TOP
+            if (node >= VRT_TOP_BASE) {
+                const float4* n = g_lds_top + 8 * (node - VRT_TOP_BASE);
+                lx = n[0]; ly = n[1]; lz = n[2]; hx = n[3]; hy = n[4]; hz = n[5]; cc = n[6];
+            } else
+#endif
+            {
+                const float4* n = S.bvh4 + 8 * (size_t)node;
+                lx = n[0]; ly = n[1]; lz = n[2]; hx = n[3]; hy = n[4]; hz = n[5]; cc = n[6];
+            }
             const float lim = best.prim >= 0 ? best.t : lim0;
             int c0 = __float_as_int(cc.x), c1 = __float_as_int(cc.y), c2 = __float_as_int(cc.z), c3 = __float_as_int(cc.w);
             float t0, t1, t2, t3;
