@@ -82,7 +82,7 @@ __global__ __launch_bounds__(VRT_MEGA_THREADS, BVH ? VRT_BVH_WAVES : 4) void k_m
     const int v = (bx << pw_shift) + (pi & ((1 << pw_shift) - 1));
     const int r = (by << (pshift - pw_shift)) + (pi >> pw_shift);
     const int h = local_to_global_row(P, r);
-    if (BVH) stage_bvh_top(S);
+    if (BVH) stage_bvh_top(S); else stage_prims(S);
     Counters C = {0, 0, 0, 0, 0, 0};
     Recorder R; R.segs = nullptr; R.cap = 0; R.n = 0; R.sample = 0;
     const bool inside = v < cam.width && r < P.local_rows && h < cam.height;
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(64) void k_pixels(DevScene S, DevCam cam, DevParams
                                                int* __restrict__ hit_out, unsigned long long* ctr)
 {
     int i = blockIdx.x * 64 + threadIdx.x;
-    if (BVH) stage_bvh_top(S);
+    if (BVH) stage_bvh_top(S); else stage_prims(S);
     Counters C = {0, 0, 0, 0, 0, 0};
     __shared__ LdsScene s_scene;
     stage_scene(S, &s_scene);
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(64) void k_ray(DevScene S, DevParams P, float ox, f
                                             float dz, int depth, float4* __restrict__ rgba_out,
                                             int* __restrict__ hit_out, unsigned long long* ctr)
 {
-    if (BVH) stage_bvh_top(S);
+    if (BVH) stage_bvh_top(S); else stage_prims(S);
     Counters C = {0, 0, 0, 0, 0, 0};
     if (threadIdx.x == 0) {
         Recorder R; R.segs = nullptr; R.cap = 0; R.n = 0; R.sample = 0;

@@ -197,6 +197,31 @@ __device__ __forceinline__ void test_prim(const DevScene& S, int id, f3 o, f3 d,
 // testing i, and a division-free path for axis-aligned boxes, were both measured slower on
 // MI355X and are not used.)
 // ANY: stop at the first primitive hit with t < tlim (and t <= maxd).
+// VRT_LDS_PRIMS=1 (study build) reads the primitives of the brute-force loop from a copy in LDS
+// (whole block calls stage_prims once) instead of through the scalar cache into SGPRs.
+#ifndef VRT_LDS_PRIMS
+#define VRT_LDS_PRIMS 0
+#endif
+#define VRT_BRUTE_MAX 48
+#if VRT_LDS_PRIMS
+__shared__ float4 g_lds_sph[VRT_BRUTE_MAX], g_lds_aab[2 * VRT_BRUTE_MAX], g_lds_pre[VRT_BRUTE_MAX];
+__device__ __forceinline__ void stage_prims(const DevScene& S)
+{
+    for (int k = threadIdx.x; k < S.n_sph; k += blockDim.x) g_lds_sph[k] = S.sph[k];
+    if (S.all_aab) for (int k = threadIdx.x; k < 2 * S.n_box; k += blockDim.x) g_lds_aab[k] = S.aab[k];
+    if (S.cam_pre) for (int k = threadIdx.x; k < S.n_sph + S.n_box; k += blockDim.x) g_lds_pre[k] = S.cam_pre[k];
+    __syncthreads();
+}
+#define VRT_SPH(i) g_lds_sph[i]
+#define VRT_AAB(i) g_lds_aab[i]
+#define VRT_PRE(i) g_lds_pre[i]
+#else
+__device__ __forceinline__ void stage_prims(const DevScene&) {}
+#define VRT_SPH(i) S.sph[i]
+#define VRT_AAB(i) S.aab[i]
+#define VRT_PRE(i) S.cam_pre[i]
+#endif
+
 // CAM: the ray starts at the camera origin and S.cam_pre holds the per-primitive terms that
 // depend only on the origin.
 #ifndef VRT_AAB_CULL
@@ -209,7 +234,7 @@ __device__ __forceinline__ Hit intersect_brute(const DevScene& S, f3 o, f3 d, fl
     if (is_zero3(d)) return best;
     for (int i = 0; i < S.n_sph; ++i) {
         float t;
-        bool h = CAM ? hit_sphere_pre(S.cam_pre[i], d, maxd, t) : hit_sphere(S.sph[i], o, d, maxd, t);
+        bool h = CAM ? hit_sphere_pre(VRT_PRE(i), d, maxd, t) : hit_sphere(VRT_SPH(i), o, d, maxd, t);
         if (i != skip && h && t < best.t && t < tlim) {
             best.t = t; best.prim = i;
             if (ANY) return best;
@@ -220,8 +245,8 @@ __device__ __forceinline__ Hit intersect_brute(const DevScene& S, f3 o, f3 d, fl
         const f3 inv = mk3(1.f / d.x, 1.f / d.y, 1.f / d.z);
         for (int i = 0; i < S.n_box; ++i) {
             float t; int aux;
-            const float4 a0 = S.aab[2 * i], a1 = S.aab[2 * i + 1];
-            const f3 p = CAM ? xyz(S.cam_pre[S.n_sph + i]) : o - xyz(a0);
+            const float4 a0 = VRT_AAB(2 * i), a1 = VRT_AAB(2 * i + 1);
+            const f3 p = CAM ? xyz(VRT_PRE(S.n_sph + i)) : o - xyz(a0);
 #if VRT_AAB_CULL
             float oo = dot3(p, p), bb = dot3(p, d);
             float cs = oo - a1.w, slack = 4e-6f * oo;

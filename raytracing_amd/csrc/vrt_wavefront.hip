@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256, 4) void k_wf_primary(DevScene S, DevCam cam, D
     const int r = row0 + rb;
     const int h = local_to_global_row(P, r);
     const bool inside = tile < n_tiles && v < cam.width && rb < band_rows && r < P.local_rows && h < cam.height;
-    if (BVH) stage_bvh_top(S);
+    if (BVH) stage_bvh_top(S); else stage_prims(S);
     Counters C = {0, 0, 0, 0, 0, 0};
     const f3 O = mk3(cam.ox, cam.oy, cam.oz);
     f3 raw = mk3(0.f, 0.f, 0.f);
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void k_wf_bounce(DevScene S, DevParams P, WfWo
     const RayQueue& in = W.q[(depth - 1) & 1];
     int count = W.counts[depth - 1];
     if (count > (int)W.cap) count = (int)W.cap;
-    if (BVH) stage_bvh_top(S);
+    if (BVH) stage_bvh_top(S); else stage_prims(S);
     Counters C = {0, 0, 0, 0, 0, 0};
     int stride = gridDim.x * 256;
     // wave-uniform trip count: every lane of a wave runs the same number of iterations so
