@@ -61,11 +61,16 @@ __device__ __forceinline__ void flush_counters(const Counters& C, unsigned long 
 #ifndef VRT_BVH_WAVES
 #define VRT_BVH_WAVES 4
 #endif
-template <bool BVH, bool TWOCHILD, bool SPLIT>
-__global__ __launch_bounds__(VRT_MEGA_THREADS, BVH ? VRT_BVH_WAVES : 4) void k_mega(DevScene S, DevCam cam, DevParams P, float4* __restrict__ rgba,
+// SIMPLE (brute-force scenes only) is the instantiation for scenes of spheres and world-axis boxes
+// without triangles or textures, such as the shipped teaching scene: with those facts known at
+// compile time the unused loops and branches, and the registers they keep alive, disappear.
+template <bool BVH, bool TWOCHILD, bool SPLIT, bool SIMPLE>
+__global__ __launch_bounds__(VRT_MEGA_THREADS, BVH ? VRT_BVH_WAVES : 4) void k_mega(DevScene S_in, DevCam cam, DevParams P, float4* __restrict__ rgba,
                                               int* __restrict__ hit_id, unsigned long long* ctr,
                                               int blocks_x, int n_blocks)
 {
+    DevScene S = S_in;
+    if (SIMPLE) { S.n_tri = 0; S.all_aab = 1; S.mat_tex = nullptr; S.n_big = 0; S.tri = nullptr; } // S.box stays: face normals
     unsigned bid = blockIdx.x;
     {   // bijective XCD remap: label = bid % 8 selects a contiguous band of block ids
         unsigned q = n_blocks / 8, r = n_blocks % 8, xcd = bid % 8, k = bid / 8;
@@ -215,10 +220,15 @@ hipError_t vrt_launch_mega(const DevScene& S, const DevCam& cam, const DevParams
     int n_blocks = blocks_x * blocks_y;
     if (n_blocks <= 0) return hipSuccess;
     dim3 grid(n_blocks), block(VRT_MEGA_THREADS);
-#define VRT_GO(B, T) do { if (shift == 0) hipLaunchKernelGGL((k_mega<B, T, false>), grid, block, 0, stream, S, cam, P, rgba, hit_id, ctr, blocks_x, n_blocks); \
-                         else hipLaunchKernelGGL((k_mega<B, T, true>), grid, block, 0, stream, S, cam, P, rgba, hit_id, ctr, blocks_x, n_blocks); } while (0)
+    const bool simple = !bvh && S.n_tri == 0 && S.all_aab && !S.mat_tex;
+#define VRT_GO3(B, T, SP, SI) hipLaunchKernelGGL((k_mega<B, T, SP, SI>), grid, block, 0, stream, S, cam, P, rgba, hit_id, ctr, blocks_x, n_blocks)
+#define VRT_GO(B, T) do { if (shift == 0) VRT_GO3(B, T, false, false); else VRT_GO3(B, T, true, false); } while (0)
+#define VRT_GOS(T) do { if (shift == 0) VRT_GO3(false, T, false, true); else VRT_GO3(false, T, true, true); } while (0)
     if (bvh) { if (twochild) VRT_GO(true, true); else VRT_GO(true, false); }
+    else if (simple) { if (twochild) VRT_GOS(true); else VRT_GOS(false); }
     else     { if (twochild) VRT_GO(false, true); else VRT_GO(false, false); }
+#undef VRT_GOS
+#undef VRT_GO3
 #undef VRT_GO
     return hipGetLastError();
 }
