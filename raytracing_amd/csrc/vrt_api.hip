@@ -37,7 +37,12 @@ struct vrt_ctx {
     bool have_cam = false;
     // per-call buffers
     float2* d_offsets = nullptr; size_t offsets_cap = 0;
-    unsigned long long* d_ctr = nullptr;
+    unsigned long long* d_ctr = nullptr;       // counter block of the multi-kernel paths, cleared per call
+    // The megakernel path takes its counter block from a ring of kCtrRing blocks that is cleared
+    // with one fill every kCtrRing frames instead of one fill launch (~5 us) per frame.
+    unsigned long long* d_ctr_ring = nullptr;
+    unsigned ring_next = 0;
+    unsigned long long* last_ctr = nullptr;    // block the last call counted into
     float4* d_rgba = nullptr; int* d_hit = nullptr; size_t fb_cap = 0;
     int* d_rec_pixels = nullptr; vrt_path_seg* d_segs = nullptr; int* d_seg_counts = nullptr;
     size_t rec_px_cap = 0, rec_seg_cap = 0;
@@ -48,6 +53,9 @@ struct vrt_ctx {
     uint64_t last_pixels = 0; int last_mode = 0;
     bool timed = false;
 };
+
+static const unsigned kCtrRing = 64;
+static const size_t kCtrBlock = VRT_CTR_SLOTS * VRT_CTR_STRIDE; // 64-bit words per counter block
 
 static int fail(vrt_ctx* c, int code, const std::string& msg)
 {
@@ -103,6 +111,7 @@ extern "C" int vrt_create(int device, vrt_ctx** out)
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming) != hipSuccess ||
         hipMalloc(&c->d_ctr, VRT_CTR_SLOTS * VRT_CTR_STRIDE * sizeof(unsigned long long)) != hipSuccess ||
+        hipMalloc(&c->d_ctr_ring, kCtrRing * kCtrBlock * sizeof(unsigned long long)) != hipSuccess ||
         hipMalloc(&c->d_px_rgba, sizeof(float4)) != hipSuccess ||
         hipMalloc(&c->d_px_hit, sizeof(int)) != hipSuccess) {
         delete c;
@@ -139,7 +148,7 @@ extern "C" int vrt_destroy(vrt_ctx* c)
     hipStreamSynchronize(c->stream);
     free_scene(c);
     free_wf(c);
-    hipFree(c->d_offsets); hipFree(c->d_ctr); hipFree(c->d_rgba); hipFree(c->d_hit);
+    hipFree(c->d_offsets); hipFree(c->d_ctr); hipFree(c->d_ctr_ring); hipFree(c->d_rgba); hipFree(c->d_hit);
     hipFree(c->d_rec_pixels); hipFree(c->d_segs); hipFree(c->d_seg_counts);
     hipFree(c->d_px_rgba); hipFree(c->d_px_hit);
     hipEventDestroy(c->ev0); hipEventDestroy(c->ev1); hipEventDestroy(c->ev_done);
@@ -522,7 +531,6 @@ static int ensure_wf(vrt_ctx* c, size_t slots, bool two)
 static int enqueue_frame(vrt_ctx* c, const vrt_params* p, const DevParams& P, float4* rgba, int* hit,
                          hipStream_t stream)
 {
-    HIPCHK(c, hipMemsetAsync(c->d_ctr, 0, VRT_CTR_SLOTS * VRT_CTR_STRIDE * sizeof(unsigned long long), stream));
     bool two = (p->flags & VRT_FIX_DIELECTRIC) != 0;
     int mode = p->mode == VRT_MODE_WAVEFRONT ? VRT_MODE_WAVEFRONT : VRT_MODE_MEGAKERNEL;
     if (mode == VRT_MODE_WAVEFRONT) {
@@ -539,9 +547,17 @@ static int enqueue_frame(vrt_ctx* c, const vrt_params* p, const DevParams& P, fl
         if (rc) return rc;
         WfWorkspace wf = c->wf;
         wf.slots = want; // a workspace kept from a larger frame still runs this frame in bands of `want`
+        HIPCHK(c, hipMemsetAsync(c->d_ctr, 0, kCtrBlock * sizeof(unsigned long long), stream));
+        c->scene.dbg = c->d_ctr; c->last_ctr = c->d_ctr;
         HIPCHK(c, vrt_launch_wavefront(c->scene, c->cam, P, c->use_bvh, two, wf, rgba, hit, c->d_ctr, stream));
     } else {
-        HIPCHK(c, vrt_launch_mega(c->scene, c->cam, P, c->use_bvh, two, rgba, hit, c->d_ctr, stream));
+        const unsigned slot = c->ring_next % kCtrRing;
+        if (slot == 0)   // frames on one stream run in order, so every block is clean when its turn comes
+            HIPCHK(c, hipMemsetAsync(c->d_ctr_ring, 0, kCtrRing * kCtrBlock * sizeof(unsigned long long), stream));
+        c->ring_next++;
+        unsigned long long* ctr = c->d_ctr_ring + (size_t)slot * kCtrBlock;
+        c->scene.dbg = ctr; c->last_ctr = ctr;
+        HIPCHK(c, vrt_launch_mega(c->scene, c->cam, P, c->use_bvh, two, rgba, hit, ctr, stream));
     }
     c->last_pixels = (uint64_t)P.local_rows * c->cam.width;
     c->last_mode = mode;
@@ -551,7 +567,8 @@ static int enqueue_frame(vrt_ctx* c, const vrt_params* p, const DevParams& P, fl
 static int read_stats(vrt_ctx* c, vrt_stats* s)
 {
     std::vector<unsigned long long> h(VRT_CTR_SLOTS * VRT_CTR_STRIDE);
-    HIPCHK(c, hipMemcpy(h.data(), c->d_ctr, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(h.data(), c->last_ctr ? c->last_ctr : c->d_ctr, h.size() * sizeof(unsigned long long),
+                        hipMemcpyDeviceToHost));
     memset(s, 0, sizeof *s);
     for (int i = 0; i < VRT_CTR_SLOTS; ++i)
         for (int k = 0; k < VRT_RAY_CLASSES; ++k) s->rays[k] += h[i * VRT_CTR_STRIDE + k];
@@ -730,6 +747,7 @@ extern "C" int vrt_trace_pixel(vrt_ctx* c, const vrt_params* p, int h, int v, in
     if (cap < 0 || (cap > 0 && !segs)) return fail(c, VRT_ERR_INVALID, "bad record buffer");
     int pix = h * c->cam.width + v, n = 0;
     HIPCHK(c, hipMemsetAsync(c->d_ctr, 0, VRT_CTR_SLOTS * VRT_CTR_STRIDE * sizeof(unsigned long long), c->stream));
+    c->scene.dbg = c->d_ctr; c->last_ctr = c->d_ctr;
     rc = run_records(c, p, P, &pix, 1, cap, sample < 0 ? -1 : sample, segs, &n, c->d_px_rgba, c->d_px_hit, c->d_ctr);
     if (rc) return rc;
     float4 col; int id;
@@ -754,6 +772,7 @@ extern "C" int vrt_trace_ray(vrt_ctx* c, const vrt_params* p, const float origin
     if (rc) return rc;
     HIPCHK(c, hipMemsetAsync(c->d_ctr, 0, VRT_CTR_SLOTS * VRT_CTR_STRIDE * sizeof(unsigned long long), c->stream));
     bool two = (p->flags & VRT_FIX_DIELECTRIC) != 0;
+    c->scene.dbg = c->d_ctr; c->last_ctr = c->d_ctr;
     HIPCHK(c, vrt_launch_ray(c->scene, P, c->use_bvh, two, origin, direction, depth, c->d_px_rgba, c->d_px_hit,
                              c->d_ctr, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
