@@ -61,11 +61,14 @@ __device__ __forceinline__ void flush_counters(const Counters& C, unsigned long 
 #ifndef VRT_BVH_WAVES
 #define VRT_BVH_WAVES 4
 #endif
+#ifndef VRT_SIMPLE_WAVES
+#define VRT_SIMPLE_WAVES 4
+#endif
 // SIMPLE (brute-force scenes only) is the instantiation for scenes of spheres and world-axis boxes
 // without triangles or textures, such as the shipped teaching scene: with those facts known at
 // compile time the unused loops and branches, and the registers they keep alive, disappear.
 template <bool BVH, bool TWOCHILD, bool SPLIT, bool SIMPLE>
-__global__ __launch_bounds__(VRT_MEGA_THREADS, BVH ? VRT_BVH_WAVES : 4) void k_mega(DevScene S_in, DevCam cam, DevParams P, float4* __restrict__ rgba,
+__global__ __launch_bounds__(VRT_MEGA_THREADS, BVH ? VRT_BVH_WAVES : (SIMPLE ? VRT_SIMPLE_WAVES : 4)) void k_mega(DevScene S_in, DevCam cam, DevParams P, float4* __restrict__ rgba,
                                               int* __restrict__ hit_id, unsigned long long* ctr,
                                               int blocks_x, int n_blocks)
 {
