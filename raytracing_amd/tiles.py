@@ -29,8 +29,8 @@ class FrameGather:
     """Gathers packed strips to rank 0 and puts them back in row order.
 
     Every rank passes a buffer of `rows_max` rows (ranks that own fewer leave the tail unused)
-    so that the gather moves equal-sized messages; rank 0 then scatters the valid rows into
-    the full frame with one index_copy."""
+    so that the gather moves equal-sized messages; rank 0 then scatters the rows into the full
+    frame with one index_copy (unused tail rows land in a spare row)."""
 
     def __init__(self, height, width, channels, world, rank, tile_rows, device, dtype=torch.float32,
                  group=None):
@@ -39,17 +39,19 @@ class FrameGather:
         self.rows_max = max_owned_rows(height, world, tile_rows)
         self.local = torch.zeros((self.rows_max, width, channels), dtype=dtype, device=device)
         self.n_local = len(owned_rows(height, rank, world, tile_rows))
-        self.gathered = self.final = self.src_index = self.dst_index = None
+        self.gathered = self.final = self._final_buf = self.dst_index = None
         if rank == 0:
-            self.final = torch.zeros((height, width, channels), dtype=dtype, device=device)
+            # one spare row at the end takes the unused tail rows of ranks that own fewer rows, so
+            # that the de-interleave is a single index_copy over everything received
+            self._final_buf = torch.zeros((height + 1, width, channels), dtype=dtype, device=device)
+            self.final = self._final_buf[:height]
             if world > 1:
                 self.gathered = torch.zeros((world, self.rows_max, width, channels), dtype=dtype, device=device)
-                src, dst = [], []
+                dst = []
                 for k in range(world):
                     rows = owned_rows(height, k, world, tile_rows)
-                    src.extend(k * self.rows_max + j for j in range(len(rows)))
                     dst.extend(rows)
-                self.src_index = torch.tensor(src, dtype=torch.long, device=device)
+                    dst.extend([height] * (self.rows_max - len(rows)))
                 self.dst_index = torch.tensor(dst, dtype=torch.long, device=device)
 
     def gather(self):
@@ -60,8 +62,7 @@ class FrameGather:
             return self.final
         if self.rank == 0:
             dist.gather(self.local, list(self.gathered.unbind(0)), dst=0, group=self.group)
-            flat = self.gathered.view(self.world * self.rows_max, self.w, self.c)
-            self.final.index_copy_(0, self.dst_index, flat.index_select(0, self.src_index))
+            self._deinterleave()
             return self.final
         dist.gather(self.local, None, dst=0, group=self.group)
         return None
@@ -84,7 +85,10 @@ class FrameGather:
             return self.final
         handle.wait()
         if self.rank == 0:
-            flat = self.gathered.view(self.world * self.rows_max, self.w, self.c)
-            self.final.index_copy_(0, self.dst_index, flat.index_select(0, self.src_index))
+            self._deinterleave()
             return self.final
         return None
+
+    def _deinterleave(self):
+        flat = self.gathered.view(self.world * self.rows_max, self.w, self.c)
+        self._final_buf.index_copy_(0, self.dst_index, flat)
