@@ -137,6 +137,8 @@ def scaling_8k(local_rank, world, rank, dev, cdev, rehearsal, frames, tile_rows,
     ranks (strong scaling) and gathered to rank 0 with RCCL.  Timed like the main loop: barrier
     and device synchronisation on both sides, maximum over ranks.  Returns a dict on rank 0."""
     scene, cam, offsets, kw, label = build_workload("c5", world)
+    if world > 1:
+        scene = tiles.broadcast_scene(scene if rank == 0 else ra.Scene(), cdev)
     W, H = cam.width, cam.height
     ctx = host.Context(local_rank)
     ctx.set_scene(scene)
@@ -251,6 +253,10 @@ def main():
     cdev = torch.device("cpu") if rehearsal else dev
 
     scene, cam, offsets, kw, label = build_workload(args.workload, world)
+    if world > 1:
+        # the scene description lives on rank 0 (the host that marshalled it) and is replicated
+        # to the other ranks before each uploads it to its own GPU
+        scene = tiles.broadcast_scene(scene if rank == 0 else ra.Scene(), cdev)
     mode = {"auto": abi.VRT_MODE_AUTO, "mega": abi.VRT_MODE_MEGAKERNEL, "wavefront": abi.VRT_MODE_WAVEFRONT}[args.mode]
     prm = ra.Params(offsets=offsets, mode=mode, tile_index=rank, tile_count=world, tile_rows=args.tile_rows,
                     compact_rows=True, **kw)
@@ -391,6 +397,7 @@ def main():
             "config": {"workload": label, "frame": [W, H], "rays_per_frame": queries,
                        "mode": "wavefront" if st.mode_used == abi.VRT_MODE_WAVEFRONT else "megakernel",
                        "gather": "rccl gather to rank 0, overlapped with the next frame" if world > 1 else "none",
+                       "scene": "broadcast from rank 0" if world > 1 else "local",
                        "rays_by_class": {n: int(r) for n, r in zip(abi.RAY_CLASS_NAMES, rays)}},
             "ms_per_frame_kernel": kernel_ms,
             "roofline": roof,

@@ -5,6 +5,7 @@ are independent, so the only exchange is the final gather of the strips to rank 
 (torch.distributed: RCCL over xGMI for GPU tensors, gloo for CPU tensors in the tests).
 libvrt renders a rank's strips packed in ascending row order (vrt_params.compact_rows).
 """
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -92,3 +93,69 @@ class FrameGather:
     def _deinterleave(self):
         flat = self.gathered.view(self.world * self.rows_max, self.w, self.c)
         self._final_buf.index_copy_(0, self.dst_index, flat)
+
+
+# ---- scene replication: rank 0 owns the scene description (in the Unity host: the process that
+# marshalled the colliders), every other rank receives a byte-identical copy before it uploads it
+# to its own GPU.  One broadcast of a small header with the array sizes, then one per array.
+
+_SCENE_ARRAYS = ("spheres", "boxes", "vertices", "indices", "tri_material", "materials", "lights", "uvs")
+
+
+def broadcast_scene(scene, device, src=0, group=None):
+    """Collective.  Rank `src` passes its Scene, the others pass a fresh Scene(); returns the
+    scene every rank should upload.  `device` is where the transfer buffers live (the rank's GPU
+    for RCCL, CPU for gloo)."""
+    rank = dist.get_rank(group)
+    n_tex = torch.zeros(1, dtype=torch.int64, device=device)
+    header = torch.zeros(len(_SCENE_ARRAYS), dtype=torch.int64, device=device)
+    if rank == src:
+        sizes = [(-1 if getattr(scene, k) is None else np.ascontiguousarray(getattr(scene, k)).nbytes)
+                 for k in _SCENE_ARRAYS]
+        header.copy_(torch.tensor(sizes, dtype=torch.int64))
+        n_tex[0] = len(scene.textures)
+    dist.broadcast(header, src, group=group)
+    dist.broadcast(n_tex, src, group=group)
+    proto = type(scene)()
+    for k, nbytes in zip(_SCENE_ARRAYS, header.tolist()):
+        if nbytes < 0:
+            setattr(scene, k, None)
+            continue
+        like = getattr(proto, k)
+        dtype = {"tri_material": np.dtype(np.int32), "uvs": np.dtype(np.float32)}.get(k, None if like is None else like.dtype)
+        buf = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
+        if rank == src and nbytes:
+            buf[:nbytes].copy_(torch.from_numpy(np.ascontiguousarray(getattr(scene, k)).view(np.uint8).reshape(-1).copy()))
+        dist.broadcast(buf, src, group=group)
+        if rank != src:
+            arr = np.frombuffer(buf[:nbytes].cpu().numpy().tobytes(), dtype=dtype).copy()
+            tail = {"vertices": (-1, 3), "indices": (-1, 3), "uvs": (-1, 2)}.get(k)
+            setattr(scene, k, arr.reshape(tail) if tail else arr)
+    # shading constants, material textures and textures
+    sh_bytes = bytes(scene.shading) if rank == src else bytes(len(bytes(scene.shading)))
+    sh = torch.tensor(list(sh_bytes), dtype=torch.uint8, device=device)
+    dist.broadcast(sh, src, group=group)
+    if rank != src:
+        scene.shading = type(scene.shading).from_buffer_copy(bytes(sh.cpu().tolist()))
+    mt = torch.full((max(len(scene.materials), 1),), -1, dtype=torch.int64, device=device)
+    if rank == src and scene.mat_texture:
+        vals = list(scene.mat_texture) + [-1] * (len(scene.materials) - len(scene.mat_texture))
+        mt[: len(scene.materials)].copy_(torch.tensor(vals[: len(scene.materials)], dtype=torch.int64))
+    dist.broadcast(mt, src, group=group)
+    if rank != src:
+        scene.mat_texture = mt[: len(scene.materials)].tolist()
+        scene.textures = []
+    for t in range(int(n_tex[0])):
+        meta = torch.zeros(3, dtype=torch.int64, device=device)
+        if rank == src:
+            img, wrap = scene.textures[t]
+            meta.copy_(torch.tensor([img.shape[0], img.shape[1], wrap], dtype=torch.int64))
+        dist.broadcast(meta, src, group=group)
+        h, w, wrap = meta.tolist()
+        tex = torch.empty((h, w, 4), dtype=torch.float32, device=device)
+        if rank == src:
+            tex.copy_(torch.from_numpy(scene.textures[t][0]))
+        dist.broadcast(tex, src, group=group)
+        if rank != src:
+            scene.textures.append((tex.cpu().numpy().copy(), int(wrap)))
+    return scene

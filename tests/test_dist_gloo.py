@@ -69,3 +69,46 @@ def test_owned_rows_partition():
         seen = sorted(r for k in range(n) for r in tiles.owned_rows(h, k, n, tr))
         assert seen == list(range(h))
         assert tiles.max_owned_rows(h, n, tr) >= (h + n - 1) // n
+
+
+def _bcast_worker(rank, world, port, which, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    make = {"teaching": ra.teaching_scene, "mesh": lambda: ra.tessellated_mesh_scene(quads=6),
+            "textured": lambda: ra.textured_quad_scene(1, 3.0)}[which]
+    scene = make() if rank == 0 else ra.Scene()
+    scene = tiles.broadcast_scene(scene, torch.device("cpu"))
+    d = scene.desc()  # must be a valid description on every rank
+    assert d.n_materials == len(scene.materials)
+    if rank == 1:
+        import pickle
+        with open(out_path, "wb") as f:
+            pickle.dump({k: getattr(scene, k) for k in tiles._SCENE_ARRAYS}
+                        | {"shading": bytes(scene.shading), "mat_texture": list(scene.mat_texture),
+                           "textures": scene.textures}, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("which", ["teaching", "mesh", "textured"])
+def test_scene_broadcast_is_byte_identical(tmp_path, which):
+    """The scene every other rank uploads is the one rank 0 marshalled, array by array."""
+    import pickle
+    out = str(tmp_path / "scene.pkl")
+    mp.spawn(_bcast_worker, args=(2, _free_port(), which, out), nprocs=2, join=True)
+    got = pickle.load(open(out, "rb"))
+    ref = {"teaching": ra.teaching_scene, "mesh": lambda: ra.tessellated_mesh_scene(quads=6),
+           "textured": lambda: ra.textured_quad_scene(1, 3.0)}[which]()
+    for k in tiles._SCENE_ARRAYS:
+        a, b = getattr(ref, k), got[k]
+        assert (a is None) == (b is None), k
+        if a is not None:
+            assert np.ascontiguousarray(a).tobytes() == np.ascontiguousarray(b).tobytes(), k
+            assert np.asarray(a).shape == np.asarray(b).shape, k
+    assert bytes(ref.shading) == got["shading"]
+    want_mt = list(ref.mat_texture) + [-1] * (len(ref.materials) - len(ref.mat_texture))
+    assert got["mat_texture"] == want_mt or (not ref.textures and set(got["mat_texture"]) <= {-1})
+    assert len(got["textures"]) == len(ref.textures)
+    for (ia, wa), (ib, wb) in zip(ref.textures, got["textures"]):
+        assert wa == wb and np.array_equal(ia, ib)
