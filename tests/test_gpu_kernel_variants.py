@@ -141,3 +141,38 @@ def test_wavefront_bands_equal_megakernel(vrt_ctx, spp):
             os.environ.pop("VRT_WF_MAX_SLOTS", None)
         else:
             os.environ["VRT_WF_MAX_SLOTS"] = old
+
+
+@pytest.mark.parametrize("which", ["spheres", "mesh"])
+def test_frames_do_not_depend_on_the_tree(vrt_ctx, which):
+    """Closest hits are ranked by (t, id), so the builder (PLOC or the radix tree), the collapse
+    (surface-area-guided or every second level) and keeping scene-sized primitives in or out of
+    the tree must all give the same frame, hit ids and ray counts, bit for bit."""
+    if which == "spheres":
+        scene, cam, rng = ra.random_spheres_scene(n=1500, seed=3), ra.random_spheres_camera(120, 68), 200.0
+    else:
+        scene, cam, rng = ra.tessellated_mesh_scene(quads=40), ra.tessellated_mesh_camera(120, 68), 100.0
+    prm = ra.Params(spp=2, max_depth=5, rng=rng)
+    names = ("VRT_BUILDER", "VRT_COLLAPSE_PARITY", "VRT_NO_BIG")
+    old = {k: os.environ.get(k) for k in names}
+    results = []
+    try:
+        for env in ({}, {"VRT_BUILDER": "lbvh"}, {"VRT_COLLAPSE_PARITY": "1"},
+                    {"VRT_BUILDER": "lbvh", "VRT_COLLAPSE_PARITY": "1", "VRT_NO_BIG": "1"}):
+            for k in names:
+                os.environ.pop(k, None)
+            os.environ.update(env)
+            vrt_ctx.set_scene(scene)   # the tree is built here
+            vrt_ctx.set_camera(cam)
+            rgba, hit, st = vrt_ctx.render(prm)
+            assert st.bvh_nodes > 0
+            results.append((rgba.copy(), hit.copy(), list(st.rays)))
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    for r in results[1:]:
+        assert np.array_equal(r[0], results[0][0], equal_nan=True)
+        assert np.array_equal(r[1], results[0][1]) and r[2] == results[0][2]
