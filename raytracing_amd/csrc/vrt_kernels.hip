@@ -24,6 +24,13 @@ __device__ __forceinline__ unsigned wave_sum(unsigned v)
 // Adds this block's counters into one of VRT_CTR_SLOTS slots (one atomic per class per block).
 __device__ __forceinline__ void flush_counters(const Counters& C, unsigned long long* ctr, unsigned block_linear)
 {
+#if VRT_LDS_COUNTERS
+    __syncthreads();   // counts were added to g_lds_ctr as the rays were cast
+    if (threadIdx.x < VRT_RAY_CLASSES && g_lds_ctr[threadIdx.x])
+        atomicAdd(&ctr[(block_linear % VRT_CTR_SLOTS) * VRT_CTR_STRIDE + threadIdx.x],
+                  (unsigned long long)g_lds_ctr[threadIdx.x]);
+    return;
+#endif
     __shared__ unsigned s_ctr[VRT_RAY_CLASSES];
     if (threadIdx.x < VRT_RAY_CLASSES) s_ctr[threadIdx.x] = 0;
     __syncthreads();
@@ -92,6 +99,10 @@ __global__ __launch_bounds__(VRT_MEGA_THREADS, BVH ? VRT_BVH_WAVES : (SIMPLE ? V
     const int h = local_to_global_row(P, r);
     if (BVH) stage_bvh_top(S); else stage_prims(S);
     Counters C = {0, 0, 0, 0, 0, 0};
+#if VRT_LDS_COUNTERS
+    if (threadIdx.x < VRT_RAY_CLASSES) g_lds_ctr[threadIdx.x] = 0;
+    __syncthreads();
+#endif
     Recorder R; R.segs = nullptr; R.cap = 0; R.n = 0; R.sample = 0;
     const bool inside = v < cam.width && r < P.local_rows && h < cam.height;
 #if VRT_USE_SM
@@ -161,6 +172,10 @@ __global__ __launch_bounds__(64) void k_pixels(DevScene S, DevCam cam, DevParams
     int i = blockIdx.x * 64 + threadIdx.x;
     if (BVH) stage_bvh_top(S); else stage_prims(S);
     Counters C = {0, 0, 0, 0, 0, 0};
+#if VRT_LDS_COUNTERS
+    if (threadIdx.x < VRT_RAY_CLASSES) g_lds_ctr[threadIdx.x] = 0;
+    __syncthreads();
+#endif
     __shared__ LdsScene s_scene;
     stage_scene(S, &s_scene);
     if (i < n_pixels) {
@@ -186,6 +201,10 @@ __global__ __launch_bounds__(64) void k_ray(DevScene S, DevParams P, float ox, f
 {
     if (BVH) stage_bvh_top(S); else stage_prims(S);
     Counters C = {0, 0, 0, 0, 0, 0};
+#if VRT_LDS_COUNTERS
+    if (threadIdx.x < VRT_RAY_CLASSES) g_lds_ctr[threadIdx.x] = 0;
+    __syncthreads();
+#endif
     if (threadIdx.x == 0) {
         Recorder R; R.segs = nullptr; R.cap = 0; R.n = 0; R.sample = 0;
         f3 o = mk3(ox, oy, oz), d = normalize3(mk3(dx, dy, dz));
@@ -194,7 +213,7 @@ __global__ __launch_bounds__(64) void k_ray(DevScene S, DevParams P, float ox, f
         if (depth <= P.max_depth) {
             Hit first; first.prim = -1; first.t = INFINITY; first.aux = 0;
             if (!is_zero3(d)) {
-                if (depth == 0) C.primary++; else C.reflect++;
+                if (depth == 0) VRT_COUNT(C, primary, VRT_RAY_PRIMARY); else VRT_COUNT(C, reflect, VRT_RAY_REFLECT);
                 first = intersect<BVH, false>(S, o, d, P.range, -1);
             }
             id = first.prim;

@@ -580,6 +580,23 @@ __device__ __forceinline__ void hit_geometry(const DevScene& S, Hit h, f3 o, f3 
 
 struct Counters { unsigned precheck, primary, reflect, transmit, shadow, ao; };
 
+// VRT_LDS_COUNTERS=1 counts rays in LDS (one ds_add per wave and event, the wave's active lanes
+// counted with a ballot) instead of in six registers per lane.
+#ifndef VRT_LDS_COUNTERS
+#define VRT_LDS_COUNTERS 1
+#endif
+#if VRT_LDS_COUNTERS
+__shared__ unsigned g_lds_ctr[VRT_RAY_CLASSES];
+__device__ __forceinline__ void count_event(int k)
+{
+    unsigned long long m = __ballot(1);
+    if ((int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) atomicAdd(&g_lds_ctr[k], (unsigned)__popcll(m));
+}
+#define VRT_COUNT(C, FIELD, K) count_event(K)
+#else
+#define VRT_COUNT(C, FIELD, K) ((C).FIELD++)
+#endif
+
 struct Recorder {
     vrt_path_seg* segs; // null = off
     int cap;
@@ -630,7 +647,7 @@ __device__ __forceinline__ f3 ambient_L(const DevScene& S, const DevParams& P, f
     if (cast) {
         f3 dir = normalize3(mk3(n.x + 0.f, n.y + 0.f, n.z + 0.f));
         if (!is_zero3(dir)) {
-            C.ao++;
+            VRT_COUNT(C, ao, VRT_RAY_AO);
             Hit h = RECORD ? intersect<BVH, false>(S, point, dir, P.range, prim)
                            : intersect<BVH, true>(S, point, dir, P.range, prim);
             record_seg<RECORD>(R, point, dir, h, VRT_RAY_AO, depth, P.range);
@@ -674,7 +691,7 @@ __device__ __forceinline__ f3 phong_shade(const DevScene& S, const DevParams& P,
                 f3 loc = l.type == VRT_LIGHT_POINT ? lp : mk3(l.lx, l.ly, l.lz);
                 float dist = mag3(loc - point);
                 if (!is_zero3(sd)) {
-                    C.shadow++;
+                    VRT_COUNT(C, shadow, VRT_RAY_SHADOW);
                     // occluded iff the closest hit is nearer than the light, i.e. iff any
                     // collider is hit at t < dist; recording needs the closest hit itself
                     Hit h = RECORD ? intersect<BVH, false>(S, point, sd, 30.f, prim)
@@ -869,7 +886,7 @@ __device__ __forceinline__ f3 trace_path(const DevScene& S, const DevParams& P, 
         if (!have_first) {
             h.prim = -1; h.t = INFINITY; h.aux = 0;
             if (!is_zero3(d)) {
-                if (kind == VRT_RAY_REFLECT) C.reflect++; else C.transmit++;
+                if (kind == VRT_RAY_REFLECT) VRT_COUNT(C, reflect, VRT_RAY_REFLECT); else VRT_COUNT(C, transmit, VRT_RAY_TRANSMIT);
                 h = intersect<BVH, false>(S, o, d, P.range, skip);
                 record_seg<RECORD>(R, o, d, h, kind, depth, P.range);
             }
@@ -921,12 +938,12 @@ __device__ __forceinline__ f3 trace_sample_dev(const DevScene& S, const DevCam& 
     if (!is_zero3(d)) {
         // one closest-hit query answers both the any-hit pre-check (RayTracerUnity.cs:582)
         // and the primary TraceRay (:584); they are counted as the two queries they replace
-        C.precheck++;
+        VRT_COUNT(C, precheck, VRT_RAY_PRECHECK);
         first = intersect<BVH, false, true>(S, O, d, P.range, -1);
     }
     first_prim = first.prim;
     if (first.prim >= 0) {
-        C.primary++;
+        VRT_COUNT(C, primary, VRT_RAY_PRIMARY);
         record_seg<RECORD>(R, O, d, first, VRT_RAY_PRIMARY, 0, P.range);
         return trace_path<BVH, RECORD, TWOCHILD>(S, P, O, d, first, C, R);
     }
@@ -1076,13 +1093,13 @@ __device__ __forceinline__ float4 trace_pixel_sm(const DevScene& S, const DevCam
                 qmax = P.range; qlim = INFINITY; qskip = -1; qany = false;
                 h.prim = -1; h.t = INFINITY; h.aux = 0;
                 st = ST_CLOSEST;
-                if (!is_zero3(qd)) { C.precheck++; query = true; }
+                if (!is_zero3(qd)) { VRT_COUNT(C, precheck, VRT_RAY_PRECHECK); query = true; }
             } else if (st == ST_CLOSEST) {
                 // result of the closest-hit query for ray (qo, qd) at `depth`
                 // (Tracer/WhittedTracer.cs:33-104; at depth 0 also RayTracerUnity.cs:582-586)
                 if (depth == 0) {
                     if (i == i0 && i == 0) hit_id = h.prim;
-                    if (h.prim >= 0) { C.primary++; record_seg<RECORD>(R, qo, qd, h, VRT_RAY_PRIMARY, 0, P.range); }
+                    if (h.prim >= 0) { VRT_COUNT(C, primary, VRT_RAY_PRIMARY); record_seg<RECORD>(R, qo, qd, h, VRT_RAY_PRIMARY, 0, P.range); }
                 } else if (!is_zero3(qd)) {
                     record_seg<RECORD>(R, qo, qd, h, kind, depth, P.range);
                 }
@@ -1110,7 +1127,7 @@ __device__ __forceinline__ float4 trace_pixel_sm(const DevScene& S, const DevCam
                         cast = !(n.x < 0.f || n.z < 0.f || (n.y < 0.f && n.y != -1.f));
                     f3 dir = normalize3(mk3(n.x + 0.f, n.y + 0.f, n.z + 0.f));
                     if (cast && !is_zero3(dir)) {
-                        C.ao++;
+                        VRT_COUNT(C, ao, VRT_RAY_AO);
                         qd = dir; qmax = P.range; qlim = INFINITY; qskip = prim; qany = !RECORD;
                         st = ST_AO; query = true;
                     } else {
@@ -1141,7 +1158,7 @@ __device__ __forceinline__ float4 trace_pixel_sm(const DevScene& S, const DevCam
                         f3 loc = l.type == VRT_LIGHT_POINT ? mk3(l.vx, l.vy, l.vz) : mk3(l.lx, l.ly, l.lz);
                         dist = mag3(loc - qo);
                         if (!is_zero3(sd)) {
-                            C.shadow++;
+                            VRT_COUNT(C, shadow, VRT_RAY_SHADOW);
                             qd = sd; qmax = 30.f; qlim = RECORD ? INFINITY : dist; qskip = prim; qany = !RECORD;
                             st = ST_SHADOW; query = true; shadow_query = true;
                         }
@@ -1204,7 +1221,7 @@ __device__ __forceinline__ float4 trace_pixel_sm(const DevScene& S, const DevCam
                     qmax = P.range; qlim = INFINITY; qany = false;
                     h.prim = -1; h.t = INFINITY; h.aux = 0;
                     st = ST_CLOSEST;
-                    if (!is_zero3(qd)) { C.reflect++; query = true; }
+                    if (!is_zero3(qd)) { VRT_COUNT(C, reflect, VRT_RAY_REFLECT); query = true; }
                 } else {
                     st = ST_NEXT;
                 }
@@ -1215,7 +1232,7 @@ __device__ __forceinline__ float4 trace_pixel_sm(const DevScene& S, const DevCam
                     qmax = P.range; qlim = INFINITY; qany = false;
                     h.prim = -1; h.t = INFINITY; h.aux = 0;
                     st = ST_CLOSEST;
-                    if (!is_zero3(qd)) { if (kind == VRT_RAY_REFLECT) C.reflect++; else C.transmit++; query = true; }
+                    if (!is_zero3(qd)) { if (kind == VRT_RAY_REFLECT) VRT_COUNT(C, reflect, VRT_RAY_REFLECT); else VRT_COUNT(C, transmit, VRT_RAY_TRANSMIT); query = true; }
                 } else {
                     sum = sum + L;
                     i++; st = ST_SAMPLE;

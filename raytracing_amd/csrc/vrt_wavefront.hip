@@ -38,6 +38,13 @@ __device__ __forceinline__ unsigned wave_sum(unsigned v)
 
 __device__ __forceinline__ void flush_counters(const Counters& C, unsigned long long* ctr, unsigned block_linear)
 {
+#if VRT_LDS_COUNTERS
+    __syncthreads();   // counts were added to g_lds_ctr as the rays were cast
+    if (threadIdx.x < VRT_RAY_CLASSES && g_lds_ctr[threadIdx.x])
+        atomicAdd(&ctr[(block_linear % VRT_CTR_SLOTS) * VRT_CTR_STRIDE + threadIdx.x],
+                  (unsigned long long)g_lds_ctr[threadIdx.x]);
+    return;
+#endif
     __shared__ unsigned s_ctr[VRT_RAY_CLASSES];
     if (threadIdx.x < VRT_RAY_CLASSES) s_ctr[threadIdx.x] = 0;
     __syncthreads();
@@ -143,6 +150,10 @@ __global__ __launch_bounds__(256, 4) void k_wf_primary(DevScene S, DevCam cam, D
     const bool inside = tile < n_tiles && v < cam.width && rb < band_rows && r < P.local_rows && h < cam.height;
     if (BVH) stage_bvh_top(S); else stage_prims(S);
     Counters C = {0, 0, 0, 0, 0, 0};
+#if VRT_LDS_COUNTERS
+    if (threadIdx.x < VRT_RAY_CLASSES) g_lds_ctr[threadIdx.x] = 0;
+    __syncthreads();
+#endif
     const f3 O = mk3(cam.ox, cam.oy, cam.oz);
     f3 raw = mk3(0.f, 0.f, 0.f);
     const float2* off = nullptr;
@@ -164,10 +175,10 @@ __global__ __launch_bounds__(256, 4) void k_wf_primary(DevScene S, DevCam cam, D
             if (off) { float2 q = off[i]; ox = q.x; oy = q.y; }
             d = normalize3(mk3(raw.x + ox, raw.y + oy, raw.z));
             if (!is_zero3(d)) {
-                C.precheck++;
+                VRT_COUNT(C, precheck, VRT_RAY_PRECHECK);
                 first = intersect<BVH, false, true>(S, O, d, P.range, -1);
             }
-            if (first.prim >= 0) C.primary++;
+            if (first.prim >= 0) VRT_COUNT(C, primary, VRT_RAY_PRIMARY);
             if (i == 0 && hit_id) hit_id[(size_t)(P.compact ? r : h) * cam.width + v] = first.prim;
         }
         // RayTracerUnity.cs:582-586: a primary miss adds nothing (the sky with VRT_FIX_PRIMARY_SKY)
@@ -186,6 +197,10 @@ __global__ __launch_bounds__(256) void k_wf_bounce(DevScene S, DevParams P, WfWo
     if (count > (int)W.cap) count = (int)W.cap;
     if (BVH) stage_bvh_top(S); else stage_prims(S);
     Counters C = {0, 0, 0, 0, 0, 0};
+#if VRT_LDS_COUNTERS
+    if (threadIdx.x < VRT_RAY_CLASSES) g_lds_ctr[threadIdx.x] = 0;
+    __syncthreads();
+#endif
     int stride = gridDim.x * 256;
     // wave-uniform trip count: every lane of a wave runs the same number of iterations so
     // that the ballots in wave_append see the whole wave
@@ -202,7 +217,7 @@ __global__ __launch_bounds__(256) void k_wf_bounce(DevScene S, DevParams P, WfWo
             L = mk3(in.lr[i], in.lg[i], in.lb[i]);
             slot = in.pix[i]; skip = in.skip[i]; meta = in.meta[i];
             if (!is_zero3(d)) {
-                if ((meta >> 8) == VRT_RAY_REFLECT) C.reflect++; else C.transmit++;
+                if ((meta >> 8) == VRT_RAY_REFLECT) VRT_COUNT(C, reflect, VRT_RAY_REFLECT); else VRT_COUNT(C, transmit, VRT_RAY_TRANSMIT);
                 h = intersect<BVH, false>(S, o, d, P.range, skip);
             }
         }
