@@ -48,7 +48,7 @@ struct vrt_ctx {
     size_t rec_px_cap = 0, rec_seg_cap = 0;
     float4* d_px_rgba = nullptr; int* d_px_hit = nullptr;
     // wavefront workspace
-    WfWorkspace wf; bool wf_two = false;
+    WfWorkspace wf; bool wf_two = false; bool wf_short = false;
     // last call
     uint64_t last_pixels = 0; int last_mode = 0;
     bool timed = false;
@@ -138,6 +138,7 @@ static void free_scene(vrt_ctx* c)
 static void free_wf(vrt_ctx* c)
 {
     hipFree(c->wf.arena); hipFree(c->wf.lacc); hipFree(c->wf.counts);
+    hipFree(c->wf.hits); hipFree(c->wf.any.ox); hipFree(c->wf.any_counts);
     memset(&c->wf, 0, sizeof c->wf);
 }
 
@@ -502,15 +503,19 @@ static int prepare(vrt_ctx* c, const vrt_params* p, DevParams* out)
 }
 
 // Sample slots the wavefront workspace holds at most: a band of rows of the frame is in flight
-// at a time.  64 Mi slots are 1 GiB of radiance slots and 7.5 GiB of queues (twice that with two
-// children per hit); a frame with fewer samples gets a workspace of its own size.
+// at a time.  64 Mi slots are 1 GiB of radiance slots, 7.5 GiB of ray queues and 3.75 GiB for the
+// deferred occlusion queries (queues twice that with two children per hit); a frame with fewer samples gets a workspace of its own size.
 static const size_t kWfMaxSlots = 64ull << 20;
 
 static int ensure_wf(vrt_ctx* c, size_t slots, bool two)
 {
-    if (c->wf.slots >= slots && (c->wf_two || !two)) return VRT_OK;
+    // VRT_WF_DEFER=0 (study, tests): occlusion queries of the bounces traced where they arise
+    const char* e = getenv("VRT_WF_DEFER");
+    const bool defer = !(e && e[0] == '0');
+    if (c->wf.slots >= slots && (c->wf_two || !two) && (c->wf.hits != nullptr) == defer && !c->wf_short && !getenv("VRT_WF_ANY_CAP")) return VRT_OK;
     free_wf(c);
-    size_t cap = slots * (two ? 2 : 1);
+    c->wf_short = false;
+    size_t cap = slots * (two ? 2 : 1) + VRT_WF_SLACK;
     HIPCHK(c, hipMalloc(&c->wf.arena, cap * 2 * VRT_QUEUE_ARRAYS * sizeof(float)));
     for (int k = 0; k < 2; ++k) {
         float* b = c->wf.arena + (size_t)k * cap * VRT_QUEUE_ARRAYS;
@@ -519,10 +524,29 @@ static int ensure_wf(vrt_ctx* c, size_t slots, bool two)
         q.tr = b + 6 * cap; q.tg = b + 7 * cap; q.tb = b + 8 * cap;
         q.lr = b + 9 * cap; q.lg = b + 10 * cap; q.lb = b + 11 * cap;
         q.pix = (int*)(b + 12 * cap); q.skip = (int*)(b + 13 * cap); q.meta = (int*)(b + 14 * cap);
+        HIPCHK(c, hipMemset(q.pix, 0xff, cap * sizeof(int)));   // "unwritten" marks; consumers put them back
     }
     c->wf.cap = cap;
     HIPCHK(c, hipMalloc(&c->wf.lacc, slots * sizeof(float4)));
     HIPCHK(c, hipMalloc(&c->wf.counts, (VRT_MAX_DEPTH + 3) * sizeof(int)));
+    if (defer) {
+        // one flag word per queued ray, one query-queue entry per queued ray (a hit asks up to
+        // 1 + n_lights questions but most ask fewer than one on average; the rest is traced in place)
+        HIPCHK(c, hipMalloc(&c->wf.hits, cap * sizeof(int4)));
+        float* b = nullptr;
+        HIPCHK(c, hipMalloc(&b, cap * VRT_ANYQ_ARRAYS * sizeof(float)));
+        AnyQueue& a = c->wf.any;
+        a.ox = b; a.oy = b + cap; a.oz = b + 2 * cap; a.dx = b + 3 * cap; a.dy = b + 4 * cap; a.dz = b + 5 * cap;
+        a.tlim = b + 6 * cap; a.maxd = b + 7 * cap;
+        a.skip = (int*)(b + 8 * cap); a.target = (int*)(b + 9 * cap); a.bit = (int*)(b + 10 * cap);
+        HIPCHK(c, hipMemset(a.target, 0xff, cap * sizeof(int)));
+        c->wf.any_cap = cap;
+        if (const char* v = getenv("VRT_WF_ANY_CAP")) {   // tests: a short queue forces the in-place path
+            long long n = atoll(v);
+            if (n >= 0 && (size_t)n < cap) { c->wf.any_cap = (size_t)n; c->wf_short = true; }
+        }
+        HIPCHK(c, hipMalloc(&c->wf.any_counts, (VRT_MAX_DEPTH + 2) * sizeof(int)));
+    }
     c->wf.slots = slots; c->wf_two = two;
     return VRT_OK;
 }
@@ -542,7 +566,7 @@ static int enqueue_frame(vrt_ctx* c, const vrt_params* p, const DevParams& P, fl
         if (const char* e = getenv("VRT_WF_MAX_SLOTS")) { long long v = atoll(e); if (v > 0) max_slots = (size_t)v; } // tests: force bands
         if (want > max_slots) want = max_slots > min_band ? max_slots : min_band;
         if (want < min_band) want = min_band;
-        if (want * (two ? 2 : 1) > 0x7fffffffull) return fail(c, VRT_ERR_CAPACITY, "frame row too long for the wavefront queues");
+        if (want * (two ? 2 : 1) + VRT_WF_SLACK > 0x7fffffffull) return fail(c, VRT_ERR_CAPACITY, "frame row too long for the wavefront queues");
         int rc = ensure_wf(c, want, two);
         if (rc) return rc;
         WfWorkspace wf = c->wf;

@@ -101,6 +101,15 @@ struct RayQueue {
 };
 #define VRT_QUEUE_ARRAYS 15
 
+// Occlusion queries (ambient-occlusion and shadow rays) the wavefront pipeline traces in a pass
+// of their own; the answer of entry j is or-ed as bit `bit[j]` into the flag word of ray `target[j]`.
+struct AnyQueue {
+    float *ox, *oy, *oz, *dx, *dy, *dz; // origin, unit direction
+    float *tlim, *maxd;                 // occluded iff some collider is hit at t < tlim within maxd
+    int *skip, *target, *bit;
+};
+#define VRT_ANYQ_ARRAYS 11
+
 #define VRT_BVH_STACK 64
 #define VRT_BVH4_STACK 96
 #define VRT_BVH4_EMPTY ((int)0x80000000)

@@ -14,15 +14,27 @@ hipError_t vrt_launch_ray(const DevScene& S, const DevParams& P, bool bvh, bool 
                           const float d[3], int depth, float4* rgba_out, int* hit_out, unsigned long long* ctr,
                           hipStream_t stream);
 
+// The persistent kernels of the wavefront pipeline run at most VRT_WF_MAX_BLOCKS blocks of four
+// waves; a wave takes queue entries VRT_WF_CHUNK at a time and may leave its last chunk partly
+// unwritten, so queues are allocated VRT_WF_SLACK entries longer than the rays they must hold.
+#define VRT_WF_CHUNK 64
+#define VRT_WF_MAX_BLOCKS 4096
+#define VRT_WF_SLACK ((size_t)VRT_WF_MAX_BLOCKS * 4 * VRT_WF_CHUNK)
+
 // Wavefront pipeline workspace: ray queues (two, ping-pong), one radiance slot per sample of the
 // band of rows in flight, queue counters.
 struct WfWorkspace {
     RayQueue q[2];
     float* arena;       // backing store of both queues
-    size_t cap;         // rays per queue
+    size_t cap;         // entries per queue; unwritten ones carry a negative slot (pix)
     size_t slots;       // sample slots (pixels of a band x samples per pixel)
     float4* lacc;       // per slot: radiance of that sample (xyz)
     int* counts;        // queue sizes per depth + overflow flag, VRT_MAX_DEPTH + 3 ints
+    // deferred occlusion queries (null hits = the bounce kernel traces them on the spot)
+    int4* hits;         // per ray of the queue being worked on: (t bits, primitive, face, answer bits)
+    AnyQueue any;
+    size_t any_cap;     // queries the queue holds; what does not fit is traced on the spot
+    int* any_counts;    // queries per depth, VRT_MAX_DEPTH + 2 ints
 };
 
 hipError_t vrt_launch_wavefront(const DevScene& S, const DevCam& cam, const DevParams& P, bool bvh,

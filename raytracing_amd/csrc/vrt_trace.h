@@ -585,6 +585,9 @@ struct Counters { unsigned precheck, primary, reflect, transmit, shadow, ao; };
 #ifndef VRT_LDS_COUNTERS
 #define VRT_LDS_COUNTERS 1
 #endif
+#ifndef VRT_STUDY_NO_ANYHIT
+#define VRT_STUDY_NO_ANYHIT 0
+#endif
 #if VRT_LDS_COUNTERS
 __shared__ unsigned g_lds_ctr[VRT_RAY_CLASSES];
 __device__ __forceinline__ void count_event(int k)
@@ -630,15 +633,32 @@ __device__ __forceinline__ f3 sky_color(f3 direction)
     return a + b;
 }
 
+// How shading gets the answer to "is there a collider along this ray nearer than tlim":
+// query k = 0 is the ambient-occlusion ray of a hit, k = 1 + i the shadow ray towards light i.
+// OccInline traverses on the spot.  The wavefront pipeline has two more providers: one that
+// queues the query for a later, densely packed pass and one that reads the answers back.
+struct OccInline {
+    static constexpr bool counts = true;   // the shading pass that uses this provider counts the rays
+    template <bool BVH>
+    __device__ __forceinline__ bool occluded(const DevScene& S, int, f3 o, f3 d, float maxd, float tlim, int skip)
+    {
+#if VRT_STUDY_NO_ANYHIT   // timing study only: every query answered "free" without a traversal
+        return false;
+#else
+        return intersect<BVH, true>(S, o, d, maxd, skip, tlim).prim >= 0;
+#endif
+    }
+};
+
 // Light/AmbientOccluder.cs:56-85.  The reference builds u and v with Mathf.Pow of the normal's
 // components and shoots sp.x*u + sp.y*v + sp.z*w with the hemisphere sample sp = (0,0,1) (its
 // multi-jittered table is all zeros, Sampler/MultiJitteredSampler.cs:23-27,39).  A negative base
 // or Pow(0, negative) makes u or v NaN/Inf, 0*Inf poisons the direction, the Ray constructor
 // normalises it to zero and no ray is cast.  Working that through: the direction degenerates
 // iff n.x < 0 or n.z < 0 or (n.y < 0 and n.y != -1); otherwise it equals n.
-template <bool BVH, bool RECORD>
+template <bool BVH, bool RECORD, class OCC>
 __device__ __forceinline__ f3 ambient_L(const DevScene& S, const DevParams& P, f3 point, f3 n, int prim,
-                                        int depth, Counters& C, Recorder& R)
+                                        int depth, Counters& C, Recorder& R, OCC& occ)
 {
     bool cast = true;
     if (!(P.flags & VRT_FIX_AO_BASIS))
@@ -647,11 +667,14 @@ __device__ __forceinline__ f3 ambient_L(const DevScene& S, const DevParams& P, f
     if (cast) {
         f3 dir = normalize3(mk3(n.x + 0.f, n.y + 0.f, n.z + 0.f));
         if (!is_zero3(dir)) {
-            VRT_COUNT(C, ao, VRT_RAY_AO);
-            Hit h = RECORD ? intersect<BVH, false>(S, point, dir, P.range, prim)
-                           : intersect<BVH, true>(S, point, dir, P.range, prim);
-            record_seg<RECORD>(R, point, dir, h, VRT_RAY_AO, depth, P.range);
-            occluded = h.prim >= 0;
+            if (OCC::counts) VRT_COUNT(C, ao, VRT_RAY_AO);
+            if constexpr (RECORD) {
+                Hit h = intersect<BVH, false>(S, point, dir, P.range, prim);
+                record_seg<RECORD>(R, point, dir, h, VRT_RAY_AO, depth, P.range);
+                occluded = h.prim >= 0;
+            } else {
+                occluded = occ.template occluded<BVH>(S, 0, point, dir, P.range, INFINITY, prim);
+            }
         }
     }
     const vrt_shading& sh = S.sh;
@@ -665,13 +688,13 @@ __device__ __forceinline__ f3 ambient_L(const DevScene& S, const DevParams& P, f
 
 // Material/PhongMaterial.cs:53-89 with BRDF/LambertianBRDF.cs:23-26,54-57,
 // BRDF/GlossySpecularBRDF.cs:40-63, Light/PointLight.cs:23-51, Light/DirectionalLight.cs:22-42.
-template <bool BVH, bool RECORD>
+template <bool BVH, bool RECORD, class OCC>
 __device__ __forceinline__ f3 phong_shade(const DevScene& S, const DevParams& P, f3 point, f3 n, int prim,
                                           f3 raydir, int depth, float ka, float kd, float ks, float ex,
-                                          f3 cd, Counters& C, Recorder& R)
+                                          f3 cd, Counters& C, Recorder& R, OCC& occ)
 {
     f3 wo = -raydir;
-    f3 L = (cd * ka) * ambient_L<BVH, RECORD>(S, P, point, n, prim, depth, C, R);
+    f3 L = (cd * ka) * ambient_L<BVH, RECORD>(S, P, point, n, prim, depth, C, R, occ);
     for (int i = 0; i < S.n_lights; ++i) {
         const DevLight& l = S.lights[i];
         f3 lp = mk3(l.vx, l.vy, l.vz);
@@ -691,13 +714,16 @@ __device__ __forceinline__ f3 phong_shade(const DevScene& S, const DevParams& P,
                 f3 loc = l.type == VRT_LIGHT_POINT ? lp : mk3(l.lx, l.ly, l.lz);
                 float dist = mag3(loc - point);
                 if (!is_zero3(sd)) {
-                    VRT_COUNT(C, shadow, VRT_RAY_SHADOW);
+                    if (OCC::counts) VRT_COUNT(C, shadow, VRT_RAY_SHADOW);
                     // occluded iff the closest hit is nearer than the light, i.e. iff any
                     // collider is hit at t < dist; recording needs the closest hit itself
-                    Hit h = RECORD ? intersect<BVH, false>(S, point, sd, 30.f, prim)
-                                   : intersect<BVH, true>(S, point, sd, 30.f, prim, dist);
-                    record_seg<RECORD>(R, point, sd, h, VRT_RAY_SHADOW, depth, 30.f);
-                    if (h.prim >= 0) in_shadow = h.t < dist;
+                    if constexpr (RECORD) {
+                        Hit h = intersect<BVH, false>(S, point, sd, 30.f, prim);
+                        record_seg<RECORD>(R, point, sd, h, VRT_RAY_SHADOW, depth, 30.f);
+                        if (h.prim >= 0) in_shadow = h.t < dist;
+                    } else {
+                        in_shadow = occ.template occluded<BVH>(S, 1 + i, point, sd, 30.f, dist, prim);
+                    }
                 }
             }
             if (!in_shadow) {
@@ -785,9 +811,9 @@ struct Bounce {
 
 // Tracer/WhittedTracer.cs:49-88 (material dispatch) + Material/ReflectiveMaterial.cs:25-42 +
 // Material/DielectricMaterial.cs:56-146 + BRDF/PerfectSpecularBRDF.cs:29-39.
-template <bool BVH, bool RECORD>
+template <bool BVH, bool RECORD, class OCC>
 __device__ __forceinline__ void shade_hit(const DevScene& S, const DevParams& P, Hit h, f3 o, f3 d, int depth,
-                                          Counters& C, Recorder& R, Bounce& B)
+                                          Counters& C, Recorder& R, Bounce& B, OCC& occ)
 {
     f3 point, n;
     hit_geometry(S, h, o, d, point, n);
@@ -808,7 +834,7 @@ __device__ __forceinline__ void shade_hit(const DevScene& S, const DevParams& P,
     f3 A = mk3(0.f, 0.f, 0.f), d0 = A, w0 = A, d1 = A, w1 = A;
     if (mtype == VRT_MAT_METAL) {
         A = phong_shade<BVH, RECORD>(S, P, point, n, h.prim, d, depth, sh.metal_ka, sh.metal_kd,
-                                       sh.metal_ks, sh.metal_exp, cd, C, R);
+                                       sh.metal_ks, sh.metal_exp, cd, C, R, occ);
         f3 wo = -d;
         float ndotwo = dot3(n, wo);
         f3 wi = (-wo) + (n * 2.f) * ndotwo;
@@ -817,7 +843,7 @@ __device__ __forceinline__ void shade_hit(const DevScene& S, const DevParams& P,
         n_child = 1; d0 = normalize3(wi); w0 = fr * nd;
     } else if (mtype == VRT_MAT_DIELECTRIC) {
         A = phong_shade<BVH, RECORD>(S, P, point, n, h.prim, d, depth, sh.glass_ka, sh.glass_kd,
-                                       sh.glass_ks, sh.glass_exp, cd, C, R);
+                                       sh.glass_ks, sh.glass_exp, cd, C, R, occ);
         f3 wo = -d;
         float ndotwo = dot3(n, wo);
         f3 wi = (-wo) + (n * 2.f) * ndotwo;
@@ -842,9 +868,17 @@ __device__ __forceinline__ void shade_hit(const DevScene& S, const DevParams& P,
         }
     } else {
         A = phong_shade<BVH, RECORD>(S, P, point, n, h.prim, d, depth, sh.solid_ka, sh.solid_kd,
-                                       sh.solid_ks, sh.solid_exp, cd, C, R);
+                                       sh.solid_ks, sh.solid_exp, cd, C, R, occ);
     }
     B.prim = h.prim; B.o = point; B.n_child = n_child; B.A = A; B.d0 = d0; B.w0 = w0; B.d1 = d1; B.w1 = w1;
+}
+
+template <bool BVH, bool RECORD>
+__device__ __forceinline__ void shade_hit(const DevScene& S, const DevParams& P, Hit h, f3 o, f3 d, int depth,
+                                          Counters& C, Recorder& R, Bounce& B)
+{
+    OccInline occ;
+    shade_hit<BVH, RECORD>(S, P, h, o, d, depth, C, R, B, occ);
 }
 
 // RayTracerUnity.cs:486-517 + AntiAliasingStrategy.cs:89-90

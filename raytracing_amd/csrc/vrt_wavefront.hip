@@ -14,10 +14,19 @@
 //                 also keeps the samples of one pixel next to each other in the queue.
 //   k_wf_resolve  per pixel: sum of its slots in sample order (RayTracerUnity.cs:580-592),
 //                 average, tone-map, framebuffer write.
+// A bounce step runs as three passes when the workspace has room for deferred occlusion queries
+// (k_wf_bounce_a -> k_wf_any -> k_wf_bounce_b): the ambient-occlusion and shadow rays of scattered
+// secondary hits are cast by few lanes of a wave each (an AO ray exists for a quarter of the
+// normals, a shadow ray for half), so instead of tracing them where they arise pass a appends
+// them to a queue, k_wf_any traces that queue with full waves and pass b shades with the answers.
+// The answers, and with them every bit of the result, are those of the one-pass form.
 // With one child per hit a path owns its slot and carries its radiance in the queue entry, so
 // the arithmetic and its order are those of the megakernel's trace_path.  With two children per
 // hit (VRT_FIX_DIELECTRIC) the branches of a path share the slot and add into it atomically.
 #define VRT_STACK_LANES 256
+#ifndef VRT_WF_BOUNCE_BLOCKS
+#define VRT_WF_BOUNCE_BLOCKS 4   // blocks of 256 lanes per CU the bounce kernel is compiled for (4 waves per SIMD)
+#endif
 #include "vrt_trace.h"
 #include "vrt_launch.h"
 
@@ -81,6 +90,53 @@ __device__ __forceinline__ int wave_append(bool want, int* counter, int cap, int
     return slot;
 }
 
+// Appends of the persistent kernels: a wave takes VRT_WF_CHUNK consecutive entries of a queue
+// from the global counter with one atomic and hands them out to its lanes from a cursor in LDS
+// (`st`: base of the current chunk, entries used; owned by this wave), so that the counter, which
+// every wave of the chip shares, is touched once per 64 entries instead of once per call.  `m` =
+// the lanes that append, all of them active.  Entries at the end of a wave's last chunk stay
+// unwritten; queues mark those with a negative slot / target, and every consumer restores the
+// mark after use, so a queue is all marks whenever a producer starts on it.
+__device__ __forceinline__ int chunk_slot(unsigned long long m, volatile int* st, int* counter)
+{
+    const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1, n = __popcll(m);
+    int base = 0, used = 0, next = 0;
+    if (lane == leader) {
+        base = st[0]; used = st[1];
+        if (used + n > VRT_WF_CHUNK) {
+            next = atomicAdd(counter, VRT_WF_CHUNK);
+            st[0] = next; st[1] = used + n - VRT_WF_CHUNK;
+        } else {
+            st[1] = used + n;
+        }
+    }
+    base = __shfl(base, leader, 64); used = __shfl(used, leader, 64); next = __shfl(next, leader, 64);
+    const int p = used + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+    return p < VRT_WF_CHUNK ? base + p : next + (p - VRT_WF_CHUNK);
+}
+
+// Chunk cursors of the block's four waves: [wave][0..1] ray queue, [wave][2..3] query queue.
+__device__ __forceinline__ volatile int* chunk_state_init(int (*s)[4])
+{
+    if ((threadIdx.x & 63) == 0) {
+        int* w = s[threadIdx.x >> 6];
+        w[0] = 0; w[1] = VRT_WF_CHUNK; w[2] = 0; w[3] = VRT_WF_CHUNK;   // "chunk used up": the first append takes one
+    }
+    __syncthreads();
+    return s[threadIdx.x >> 6];
+}
+
+// wave_append through the wave's chunk cursor.  Must be called by the whole wave.
+__device__ __forceinline__ int wave_append_chunked(bool want, volatile int* st, int* counter, int cap, int* overflow)
+{
+    unsigned long long m = __ballot(want);
+    if (m == 0ull) return -1;
+    int slot = chunk_slot(m, st, counter);
+    if (!want) return -1;
+    if (slot < 0 || slot >= cap) { *overflow = 1; return -1; }
+    return slot;
+}
+
 __device__ __forceinline__ void queue_store(const RayQueue& q, int at, f3 o, f3 d, f3 T, f3 L, int slot, int skip, int meta)
 {
     q.ox[at] = o.x; q.oy[at] = o.y; q.oz[at] = o.z;
@@ -90,14 +146,44 @@ __device__ __forceinline__ void queue_store(const RayQueue& q, int at, f3 o, f3 
     q.pix[at] = slot; q.skip[at] = skip; q.meta[at] = meta;
 }
 
+// Occlusion-query provider of pass a: appends the query and answers "free"; the shading result
+// of that pass is discarded.  A query that does not fit the queue is traced on the spot.
+struct OccEmit {
+    static constexpr bool counts = true;
+    AnyQueue q; int cap; int* count; volatile int* st; unsigned* word; int target;
+    template <bool BVH>
+    __device__ __forceinline__ bool occluded(const DevScene& S, int k, f3 o, f3 d, float maxd, float tlim, int skip)
+    {
+        // the active lanes of the wave (any subset) take consecutive entries
+        const int at = chunk_slot(__ballot(1), st, count);
+        if (at >= 0 && at < cap) {
+            q.ox[at] = o.x; q.oy[at] = o.y; q.oz[at] = o.z;
+            q.dx[at] = d.x; q.dy[at] = d.y; q.dz[at] = d.z;
+            q.tlim[at] = tlim; q.maxd[at] = maxd;
+            q.skip[at] = skip; q.target[at] = target; q.bit[at] = k;
+        } else if (intersect<BVH, true>(S, o, d, maxd, skip, tlim).prim >= 0) {
+            atomicOr(word, 1u << k);
+        }
+        return false;
+    }
+};
+
+// Provider of pass b: the answers gathered in the ray's flag word.
+struct OccLookup {
+    static constexpr bool counts = false;
+    unsigned bits;
+    template <bool BVH>
+    __device__ __forceinline__ bool occluded(const DevScene&, int k, f3, f3, float, float, int) { return (bits >> k) & 1u; }
+};
+
 // The part of trace_path's loop body that follows a closest-hit query, for a path at `depth`
 // whose radiance so far is L and throughput T: adds the hit's (or the sky's) term, then either
 // finishes the path into its slot or appends it (them) to the next queue.  `shaded_ray` is false
 // for a primary miss that contributes nothing.  The whole wave must call it.
-template <bool BVH, bool TWOCHILD>
+template <bool BVH, bool TWOCHILD, class OCC>
 __device__ __forceinline__ void shade_and_spawn(const DevScene& S, const DevParams& P, bool active, bool shaded_ray,
                                                 Hit h, f3 o, f3 d, f3 T, f3 L, int depth, int slot,
-                                                const WfWorkspace& W, Counters& C)
+                                                const WfWorkspace& W, Counters& C, OCC& occ, volatile int* st)
 {
     Bounce B; B.n_child = 0;
     Recorder R; R.segs = nullptr; R.cap = 0; R.n = 0; R.sample = 0;
@@ -105,7 +191,7 @@ __device__ __forceinline__ void shade_and_spawn(const DevScene& S, const DevPara
     const bool hit = live && h.prim >= 0;
     f3 add = mk3(0.f, 0.f, 0.f);
     if (hit) {
-        shade_hit<BVH, false>(S, P, h, o, d, depth, C, R, B);
+        shade_hit<BVH, false>(S, P, h, o, d, depth, C, R, B, occ);
         add = T * B.A;
         if (depth + 1 > P.max_depth) B.n_child = 0;
     } else if (live) {
@@ -114,10 +200,13 @@ __device__ __forceinline__ void shade_and_spawn(const DevScene& S, const DevPara
     if (live) L = L + add;
     const RayQueue& out = W.q[depth & 1];
     int* overflow = &W.counts[VRT_MAX_DEPTH + 2];
-    int s0 = wave_append(hit && B.n_child >= 1, &W.counts[depth], (int)W.cap, overflow);
+    // st = the wave's chunk cursor in a persistent kernel, null in the per-tile primary kernel
+    int s0 = st ? wave_append_chunked(hit && B.n_child >= 1, st, &W.counts[depth], (int)W.cap, overflow)
+                : wave_append(hit && B.n_child >= 1, &W.counts[depth], (int)W.cap, overflow);
     if (s0 >= 0) queue_store(out, s0, B.o, B.d0, T * B.w0, L, slot, B.prim, (depth + 1) | (VRT_RAY_REFLECT << 8));
     if (TWOCHILD) {
-        int s1 = wave_append(hit && B.n_child == 2, &W.counts[depth], (int)W.cap, overflow);
+        int s1 = st ? wave_append_chunked(hit && B.n_child == 2, st, &W.counts[depth], (int)W.cap, overflow)
+                    : wave_append(hit && B.n_child == 2, &W.counts[depth], (int)W.cap, overflow);
         if (s1 >= 0) queue_store(out, s1, B.o, B.d1, T * B.w1, L, slot, B.prim, (depth + 1) | (VRT_RAY_TRANSMIT << 8));
         if (live) {   // branches share the slot: every term is added where it arises
             float* a = (float*)&W.lacc[slot];
@@ -182,14 +271,15 @@ __global__ __launch_bounds__(256, 4) void k_wf_primary(DevScene S, DevCam cam, D
             if (i == 0 && hit_id) hit_id[(size_t)(P.compact ? r : h) * cam.width + v] = first.prim;
         }
         // RayTracerUnity.cs:582-586: a primary miss adds nothing (the sky with VRT_FIX_PRIMARY_SKY)
+        OccInline occ;
         shade_and_spawn<BVH, TWOCHILD>(S, P, active, first.prim >= 0 || sky, first, O, d, mk3(1.f, 1.f, 1.f),
-                                       mk3(0.f, 0.f, 0.f), 0, slot0 + i, W, C);
+                                       mk3(0.f, 0.f, 0.f), 0, slot0 + i, W, C, occ, nullptr);
     }
     flush_counters(C, ctr, blockIdx.x);
 }
 
 template <bool BVH, bool TWOCHILD>
-__global__ __launch_bounds__(256) void k_wf_bounce(DevScene S, DevParams P, WfWorkspace W, int depth,
+__global__ __launch_bounds__(256, VRT_WF_BOUNCE_BLOCKS) void k_wf_bounce(DevScene S, DevParams P, WfWorkspace W, int depth,
                                                    unsigned long long* ctr)
 {
     const RayQueue& in = W.q[(depth - 1) & 1];
@@ -201,29 +291,127 @@ __global__ __launch_bounds__(256) void k_wf_bounce(DevScene S, DevParams P, WfWo
     if (threadIdx.x < VRT_RAY_CLASSES) g_lds_ctr[threadIdx.x] = 0;
     __syncthreads();
 #endif
+    __shared__ int s_chunk[4][4];
+    volatile int* st = chunk_state_init(s_chunk);
     int stride = gridDim.x * 256;
     // wave-uniform trip count: every lane of a wave runs the same number of iterations so
     // that the ballots in wave_append see the whole wave
     for (int base = blockIdx.x * 256 + (threadIdx.x & ~63); base < count; base += stride) {
         int i = base + (threadIdx.x & 63);
-        bool active = i < count;
+        int slot = i < count ? in.pix[i] : -1;
+        bool active = slot >= 0;   // negative slot: entry of a chunk nobody filled
         f3 o = mk3(0.f, 0.f, 0.f), d = o, T = o, L = o;
-        int slot = 0, skip = -1, meta = 0;
+        int skip = -1, meta = 0;
         Hit h; h.prim = -1; h.t = INFINITY; h.aux = 0;
         if (active) {
+            in.pix[i] = -1;   // consumed: the mark goes back
             o = mk3(in.ox[i], in.oy[i], in.oz[i]);
             d = mk3(in.dx[i], in.dy[i], in.dz[i]);
             T = mk3(in.tr[i], in.tg[i], in.tb[i]);
             L = mk3(in.lr[i], in.lg[i], in.lb[i]);
-            slot = in.pix[i]; skip = in.skip[i]; meta = in.meta[i];
+            skip = in.skip[i]; meta = in.meta[i];
             if (!is_zero3(d)) {
                 if ((meta >> 8) == VRT_RAY_REFLECT) VRT_COUNT(C, reflect, VRT_RAY_REFLECT); else VRT_COUNT(C, transmit, VRT_RAY_TRANSMIT);
                 h = intersect<BVH, false>(S, o, d, P.range, skip);
             }
         }
-        shade_and_spawn<BVH, TWOCHILD>(S, P, active, true, h, o, d, T, L, depth, slot, W, C);
+        OccInline occ;
+        shade_and_spawn<BVH, TWOCHILD>(S, P, active, true, h, o, d, T, L, depth, slot, W, C, occ, st);
     }
     flush_counters(C, ctr, blockIdx.x);
+}
+
+// Pass a of a bounce step with deferred occlusion queries: closest hit of every ray of queue
+// depth-1, kept in W.hits, and the occlusion queries of its shading appended to W.any.
+template <bool BVH>
+__global__ __launch_bounds__(256, VRT_WF_BOUNCE_BLOCKS) void k_wf_bounce_a(DevScene S, DevParams P, WfWorkspace W, int depth,
+                                                                           unsigned long long* ctr)
+{
+    const RayQueue& in = W.q[(depth - 1) & 1];
+    int count = W.counts[depth - 1];
+    if (count > (int)W.cap) count = (int)W.cap;
+    if (BVH) stage_bvh_top(S); else stage_prims(S);
+    Counters C = {0, 0, 0, 0, 0, 0};
+#if VRT_LDS_COUNTERS
+    if (threadIdx.x < VRT_RAY_CLASSES) g_lds_ctr[threadIdx.x] = 0;
+    __syncthreads();
+#endif
+    __shared__ int s_chunk[4][4];
+    volatile int* st = chunk_state_init(s_chunk);
+    const int stride = gridDim.x * 256;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < count; i += stride) {
+        if (in.pix[i] < 0) continue;   // entry of a chunk nobody filled
+        const f3 o = mk3(in.ox[i], in.oy[i], in.oz[i]);
+        const f3 d = mk3(in.dx[i], in.dy[i], in.dz[i]);
+        const int skip = in.skip[i], meta = in.meta[i];
+        Hit h; h.prim = -1; h.t = INFINITY; h.aux = 0;
+        if (!is_zero3(d)) {
+            if ((meta >> 8) == VRT_RAY_REFLECT) VRT_COUNT(C, reflect, VRT_RAY_REFLECT); else VRT_COUNT(C, transmit, VRT_RAY_TRANSMIT);
+            h = intersect<BVH, false>(S, o, d, P.range, skip);
+        }
+        W.hits[i] = make_int4(__float_as_int(h.t), h.prim, h.aux, 0);
+        if (h.prim >= 0) {
+            OccEmit occ;
+            occ.q = W.any; occ.cap = (int)W.any_cap; occ.count = &W.any_counts[depth];
+            occ.word = (unsigned*)&W.hits[i].w; occ.target = i; occ.st = st + 2;
+            Bounce B;
+            Recorder R; R.segs = nullptr; R.cap = 0; R.n = 0; R.sample = 0;
+            shade_hit<BVH, false>(S, P, h, o, d, depth, C, R, B, occ);
+        }
+    }
+    flush_counters(C, ctr, blockIdx.x);
+}
+
+// The queries pass a queued at this depth, one per lane.
+template <bool BVH>
+__global__ __launch_bounds__(256, VRT_WF_BOUNCE_BLOCKS) void k_wf_any(DevScene S, WfWorkspace W, int depth)
+{
+    int count = W.any_counts[depth];
+    if (count > (int)W.any_cap) count = (int)W.any_cap;
+    if (BVH) stage_bvh_top(S); else stage_prims(S);
+    const AnyQueue& q = W.any;
+    const int stride = gridDim.x * 256;
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < count; j += stride) {
+        const int target = q.target[j];
+        if (target < 0 || target >= (int)W.cap) continue;   // entry of a chunk nobody filled
+        q.target[j] = -1;                                   // consumed: the mark goes back
+        const f3 o = mk3(q.ox[j], q.oy[j], q.oz[j]);
+        const f3 d = mk3(q.dx[j], q.dy[j], q.dz[j]);
+        if (intersect<BVH, true>(S, o, d, q.maxd[j], q.skip[j], q.tlim[j]).prim >= 0)
+            atomicOr((unsigned*)&W.hits[target].w, 1u << (q.bit[j] & 31));
+    }
+}
+
+// Pass b: shading of every ray of queue depth-1 with the answers of k_wf_any, then as k_wf_bounce.
+template <bool BVH, bool TWOCHILD>
+__global__ __launch_bounds__(256, VRT_WF_BOUNCE_BLOCKS) void k_wf_bounce_b(DevScene S, DevParams P, WfWorkspace W, int depth)
+{
+    const RayQueue& in = W.q[(depth - 1) & 1];
+    int count = W.counts[depth - 1];
+    if (count > (int)W.cap) count = (int)W.cap;
+    Counters C = {0, 0, 0, 0, 0, 0};   // rays were counted in pass a
+    __shared__ int s_chunk[4][4];
+    volatile int* st = chunk_state_init(s_chunk);
+    const int stride = gridDim.x * 256;
+    // wave-uniform trip count, as in k_wf_bounce
+    for (int base = blockIdx.x * 256 + (threadIdx.x & ~63); base < count; base += stride) {
+        const int i = base + (threadIdx.x & 63);
+        const int slot = i < count ? in.pix[i] : -1;
+        const bool active = slot >= 0;   // negative slot: entry of a chunk nobody filled
+        f3 o = mk3(0.f, 0.f, 0.f), d = o, T = o, L = o;
+        Hit h; h.prim = -1; h.t = INFINITY; h.aux = 0;
+        OccLookup occ; occ.bits = 0u;
+        if (active) {
+            in.pix[i] = -1;   // consumed: the mark goes back
+            o = mk3(in.ox[i], in.oy[i], in.oz[i]);
+            d = mk3(in.dx[i], in.dy[i], in.dz[i]);
+            T = mk3(in.tr[i], in.tg[i], in.tb[i]);
+            L = mk3(in.lr[i], in.lg[i], in.lb[i]);
+            const int4 r = W.hits[i];
+            h.t = __int_as_float(r.x); h.prim = r.y; h.aux = r.z; occ.bits = (unsigned)r.w;
+        }
+        shade_and_spawn<BVH, TWOCHILD>(S, P, active, true, h, o, d, T, L, depth, slot, W, C, occ, st);
+    }
 }
 
 __global__ __launch_bounds__(256) void k_wf_resolve(DevCam cam, DevParams P, WfWorkspace W, int row0, int band_rows,
@@ -266,9 +454,20 @@ hipError_t run(const DevScene& S, const DevCam& cam, const DevParams& P, const W
         hipLaunchKernelGGL((k_wf_primary<BVH, TWOCHILD>), dim3((blocks_x * blocks_y + 3) / 4), dim3(256), 0, stream, S, cam,
                            P, W, row0, rows, hit_id, ctr, blocks_x, blocks_x * blocks_y);
         size_t live = (size_t)rows * per_row * (TWOCHILD ? 2 : 1);
-        int bounce_blocks = (int)((live + 255) / 256 < 4096 ? (live + 255) / 256 : 4096);
-        for (int d = 1; d <= P.max_depth; ++d)
-            hipLaunchKernelGGL((k_wf_bounce<BVH, TWOCHILD>), dim3(bounce_blocks), dim3(256), 0, stream, S, P, W, d, ctr);
+        int bounce_blocks = (int)((live + 255) / 256 < VRT_WF_MAX_BLOCKS ? (live + 255) / 256 : VRT_WF_MAX_BLOCKS);
+        if (W.hits) {
+            e = hipMemsetAsync(W.any_counts, 0, (VRT_MAX_DEPTH + 2) * sizeof(int), stream);
+            if (e != hipSuccess) return e;
+        }
+        for (int d = 1; d <= P.max_depth; ++d) {
+            if (W.hits) {
+                hipLaunchKernelGGL((k_wf_bounce_a<BVH>), dim3(bounce_blocks), dim3(256), 0, stream, S, P, W, d, ctr);
+                hipLaunchKernelGGL((k_wf_any<BVH>), dim3(bounce_blocks), dim3(256), 0, stream, S, W, d);
+                hipLaunchKernelGGL((k_wf_bounce_b<BVH, TWOCHILD>), dim3(bounce_blocks), dim3(256), 0, stream, S, P, W, d);
+            } else {
+                hipLaunchKernelGGL((k_wf_bounce<BVH, TWOCHILD>), dim3(bounce_blocks), dim3(256), 0, stream, S, P, W, d, ctr);
+            }
+        }
         hipLaunchKernelGGL(k_wf_resolve, dim3((unsigned)(((size_t)rows * cam.width + 255) / 256)), dim3(256), 0, stream,
                            cam, P, W, row0, rows, rgba);
     }

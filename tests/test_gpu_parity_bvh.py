@@ -49,8 +49,16 @@ def test_triangle_mesh_bvh(vrt_ctx, oracle_mod):
     assert (hit >= 0).mean() > 0.3
 
 
+@pytest.mark.parametrize("defer", ["deferred", "in_place", "short_queue"])
 @pytest.mark.parametrize("which", ["teaching", "spheres", "mesh"])
-def test_wavefront_equals_megakernel(vrt_ctx, oracle_mod, which):
+def test_wavefront_equals_megakernel(vrt_ctx, oracle_mod, which, defer, monkeypatch):
+    """Bounce steps with the occlusion queries queued and traced in a pass of their own (the
+    default), traced where they arise, and with a queue too short for them (the rest is traced
+    in place): all three give the megakernel's bits and ray counts."""
+    if defer == "in_place":
+        monkeypatch.setenv("VRT_WF_DEFER", "0")
+    elif defer == "short_queue":
+        monkeypatch.setenv("VRT_WF_ANY_CAP", "1000")
     if which == "teaching":
         scene, cam, rng = ra.teaching_scene(), ra.teaching_camera(200, 120), 30.0
     elif which == "spheres":
