@@ -545,7 +545,8 @@ static int ensure_wf(vrt_ctx* c, size_t slots, bool two)
             long long n = atoll(v);
             if (n >= 0 && (size_t)n < cap) { c->wf.any_cap = (size_t)n; c->wf_short = true; }
         }
-        HIPCHK(c, hipMalloc(&c->wf.any_counts, (VRT_MAX_DEPTH + 2) * sizeof(int)));
+        HIPCHK(c, hipMalloc(&c->wf.any_counts, 3 * (VRT_MAX_DEPTH + 2) * sizeof(int)));
+        c->wf.cursors = c->wf.any_counts + (VRT_MAX_DEPTH + 2);
     }
     c->wf.slots = slots; c->wf_two = two;
     return VRT_OK;
@@ -566,11 +567,13 @@ static int enqueue_frame(vrt_ctx* c, const vrt_params* p, const DevParams& P, fl
         if (const char* e = getenv("VRT_WF_MAX_SLOTS")) { long long v = atoll(e); if (v > 0) max_slots = (size_t)v; } // tests: force bands
         if (want > max_slots) want = max_slots > min_band ? max_slots : min_band;
         if (want < min_band) want = min_band;
-        if (want * (two ? 2 : 1) + VRT_WF_SLACK > 0x7fffffffull) return fail(c, VRT_ERR_CAPACITY, "frame row too long for the wavefront queues");
+        if (want * (two ? 2 : 1) + 2 * VRT_WF_SLACK > 0x7fffffffull) return fail(c, VRT_ERR_CAPACITY, "frame row too long for the wavefront queues");
         int rc = ensure_wf(c, want, two);
         if (rc) return rc;
         WfWorkspace wf = c->wf;
         wf.slots = want; // a workspace kept from a larger frame still runs this frame in bands of `want`
+        const char* r = getenv("VRT_WF_REFILL");   // 0 (study, tests): queues traced one entry per lane and pass
+        wf.refill = !(r && r[0] == '0');
         HIPCHK(c, hipMemsetAsync(c->d_ctr, 0, kCtrBlock * sizeof(unsigned long long), stream));
         c->scene.dbg = c->d_ctr; c->last_ctr = c->d_ctr;
         HIPCHK(c, vrt_launch_wavefront(c->scene, c->cam, P, c->use_bvh, two, wf, rgba, hit, c->d_ctr, stream));

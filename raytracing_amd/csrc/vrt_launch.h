@@ -17,7 +17,9 @@ hipError_t vrt_launch_ray(const DevScene& S, const DevParams& P, bool bvh, bool 
 // The persistent kernels of the wavefront pipeline run at most VRT_WF_MAX_BLOCKS blocks of four
 // waves; a wave takes queue entries VRT_WF_CHUNK at a time and may leave its last chunk partly
 // unwritten, so queues are allocated VRT_WF_SLACK entries longer than the rays they must hold.
-#define VRT_WF_CHUNK 64
+#ifndef VRT_WF_CHUNK
+#define VRT_WF_CHUNK 256
+#endif
 #define VRT_WF_MAX_BLOCKS 4096
 #define VRT_WF_SLACK ((size_t)VRT_WF_MAX_BLOCKS * 4 * VRT_WF_CHUNK)
 
@@ -35,6 +37,9 @@ struct WfWorkspace {
     AnyQueue any;
     size_t any_cap;     // queries the queue holds; what does not fit is traced on the spot
     int* any_counts;    // queries per depth, VRT_MAX_DEPTH + 2 ints
+    int* cursors;       // k_wf_trace: next unclaimed entry per depth, rays then queries, 2 * (VRT_MAX_DEPTH + 2) ints
+                        // right behind any_counts (one fill clears all three)
+    int refill;         // BVH scenes: trace queues with k_wf_trace (lanes refilled as they finish)
 };
 
 hipError_t vrt_launch_wavefront(const DevScene& S, const DevCam& cam, const DevParams& P, bool bvh,

@@ -93,7 +93,8 @@ __device__ __forceinline__ int wave_append(bool want, int* counter, int cap, int
 // Appends of the persistent kernels: a wave takes VRT_WF_CHUNK consecutive entries of a queue
 // from the global counter with one atomic and hands them out to its lanes from a cursor in LDS
 // (`st`: base of the current chunk, entries used; owned by this wave), so that the counter, which
-// every wave of the chip shares, is touched once per 64 entries instead of once per call.  `m` =
+// every wave of the chip shares, is touched once per chunk instead of once per call (an atomic on one address costs
+// about 9 ns chip-wide on MI355X, whoever issues it).  `m` =
 // the lanes that append, all of them active.  Entries at the end of a wave's last chunk stay
 // unwritten; queues mark those with a negative slot / target, and every consumer restores the
 // mark after use, so a queue is all marks whenever a producer starts on it.
@@ -323,7 +324,8 @@ __global__ __launch_bounds__(256, VRT_WF_BOUNCE_BLOCKS) void k_wf_bounce(DevScen
 
 // Pass a of a bounce step with deferred occlusion queries: closest hit of every ray of queue
 // depth-1, kept in W.hits, and the occlusion queries of its shading appended to W.any.
-template <bool BVH>
+// TRACED: the closest hits are already in W.hits (k_wf_trace ran before).
+template <bool BVH, bool TRACED>
 __global__ __launch_bounds__(256, VRT_WF_BOUNCE_BLOCKS) void k_wf_bounce_a(DevScene S, DevParams P, WfWorkspace W, int depth,
                                                                            unsigned long long* ctr)
 {
@@ -347,9 +349,14 @@ __global__ __launch_bounds__(256, VRT_WF_BOUNCE_BLOCKS) void k_wf_bounce_a(DevSc
         Hit h; h.prim = -1; h.t = INFINITY; h.aux = 0;
         if (!is_zero3(d)) {
             if ((meta >> 8) == VRT_RAY_REFLECT) VRT_COUNT(C, reflect, VRT_RAY_REFLECT); else VRT_COUNT(C, transmit, VRT_RAY_TRANSMIT);
-            h = intersect<BVH, false>(S, o, d, P.range, skip);
+            if (!TRACED) h = intersect<BVH, false>(S, o, d, P.range, skip);
         }
-        W.hits[i] = make_int4(__float_as_int(h.t), h.prim, h.aux, 0);
+        if (TRACED) {
+            const int4 r = W.hits[i];
+            h.t = __int_as_float(r.x); h.prim = r.y; h.aux = r.z;
+        } else {
+            W.hits[i] = make_int4(__float_as_int(h.t), h.prim, h.aux, 0);
+        }
         if (h.prim >= 0) {
             OccEmit occ;
             occ.q = W.any; occ.cap = (int)W.any_cap; occ.count = &W.any_counts[depth];
@@ -379,6 +386,210 @@ __global__ __launch_bounds__(256, VRT_WF_BOUNCE_BLOCKS) void k_wf_any(DevScene S
         const f3 d = mk3(q.dx[j], q.dy[j], q.dz[j]);
         if (intersect<BVH, true>(S, o, d, q.maxd[j], q.skip[j], q.tlim[j]).prim >= 0)
             atomicOr((unsigned*)&W.hits[target].w, 1u << (q.bit[j] & 31));
+    }
+}
+
+// Traversal of the 4-wide tree for a whole queue with lanes refilled as they finish: a lane
+// whose ray is done does not wait for the longest traversal of its wave, it takes the next
+// entry of the queue once VRT_WF_REFILL lanes of the wave are idle.  Queue entries are claimed
+// VRT_WF_TRACE_CHUNK at a time per wave (one atomic on the cursor all waves share), and handed
+// to idle lanes in order.
+//   ANY = false: rays of queue depth-1; closest hit (t, primitive, face, 0) to W.hits[i].
+//   ANY = true:  the occlusion queries of this depth; a hit nearer than tlim sets the answer bit.
+// The node and leaf steps are those of intersect_bvh4 (same box test, same primitive tests, same
+// ranking of candidates by (t, id)), so hits and answers are the same whatever the order.
+#ifndef VRT_WF_REFILL
+#define VRT_WF_REFILL 16
+#endif
+#define VRT_WF_TRACE_CHUNK 256
+#ifndef VRT_WF_TRACE_LDS
+#define VRT_WF_TRACE_LDS 8    // stack entries per lane in LDS: 16 KB per block, so that registers (60) bound the occupancy
+#endif
+template <bool ANY>
+__global__ __launch_bounds__(256, VRT_WF_BOUNCE_BLOCKS) void k_wf_trace(DevScene S, DevParams P, WfWorkspace W, int depth)
+{
+    __shared__ unsigned long long lds_stack[VRT_WF_TRACE_LDS * 256];
+    unsigned long long* my_lds = lds_stack + threadIdx.x;
+    unsigned long long deep[VRT_BVH4_STACK - VRT_WF_TRACE_LDS];
+    const RayQueue& in = W.q[(depth - 1) & 1];
+    const AnyQueue& q = W.any;
+    int count = ANY ? W.any_counts[depth] : W.counts[depth - 1];
+    const int cap = ANY ? (int)W.any_cap : (int)W.cap;
+    if (count > cap) count = cap;
+    int* cursor = W.cursors + (ANY ? VRT_MAX_DEPTH + 2 : 0) + depth;
+    const int lane = threadIdx.x & 63;
+    int next = 0, end = 0;            // the wave's claimed entries [next, end); wave-uniform
+    bool exhausted = count <= 0;      // wave-uniform: the cursor has passed the end of the queue
+    bool first = true;                // wave-uniform: no chunk taken yet
+    bool have = false;                // this lane is in the middle of a traversal
+    f3 o = mk3(0.f, 0.f, 0.f), d = o, inv = o;
+    float maxd = 0.f, tlim = 0.f, lim0 = 0.f;
+    int skip = -1, node = 0, sp = 0, entry = 0, bit = 0, steps_left = 0;
+    Hit best; best.t = INFINITY; best.prim = -1; best.aux = 0;
+    for (;;) {
+        const unsigned long long idle = __ballot(!have);
+        if (!exhausted && __popcll(idle) >= VRT_WF_REFILL) {
+            if (next >= end) {
+                // The first chunk of a wave is the one with its own number, taken without an atomic
+                // (atomics on one address are served one after the other chip-wide, about 9 ns each:
+                // a claim per wave at the start would cost a short queue more than its traversal);
+                // the cursor hands out what lies beyond those.
+                int b;
+                if (first) {
+                    b = (int)((blockIdx.x * 4 + (threadIdx.x >> 6)) * VRT_WF_TRACE_CHUNK);
+                    first = false;
+                } else {
+                    b = 0;
+                    if (lane == 0) b = (int)(gridDim.x * 4 * VRT_WF_TRACE_CHUNK) + atomicAdd(cursor, VRT_WF_TRACE_CHUNK);
+                    b = __builtin_amdgcn_readfirstlane(b);
+                }
+                if (b < 0 || b >= count) exhausted = true;
+                else { next = b; end = b + VRT_WF_TRACE_CHUNK < count ? b + VRT_WF_TRACE_CHUNK : count; }
+            }
+            if (!exhausted) {
+                const int n_idle = __popcll(idle);
+                const int take = n_idle < end - next ? n_idle : end - next;
+                const int r = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0u));
+                if (!have && r < take) {
+                    entry = next + r;
+                    bool valid;
+                    if (ANY) {
+                        const int target = q.target[entry];
+                        valid = target >= 0 && target < (int)W.cap;   // else: entry of a chunk nobody filled
+                        if (valid) {
+                            q.target[entry] = -1;                     // consumed: the mark goes back
+                            o = mk3(q.ox[entry], q.oy[entry], q.oz[entry]);
+                            d = mk3(q.dx[entry], q.dy[entry], q.dz[entry]);
+                            maxd = q.maxd[entry]; tlim = q.tlim[entry]; skip = q.skip[entry]; bit = q.bit[entry] & 31;
+                            entry = target;
+                        }
+                    } else {
+                        valid = in.pix[entry] >= 0;
+                        if (valid) {
+                            o = mk3(in.ox[entry], in.oy[entry], in.oz[entry]);
+                            d = mk3(in.dx[entry], in.dy[entry], in.dz[entry]);
+                            maxd = P.range; tlim = INFINITY; skip = in.skip[entry];
+                        }
+                    }
+                    if (valid) {
+                        best.t = INFINITY; best.prim = -1; best.aux = 0;
+                        bool found = false;
+                        have = !is_zero3(d);
+                        if (have) {
+                            inv = mk3(1.f / d.x, 1.f / d.y, 1.f / d.z);
+                            lim0 = fminf(maxd, tlim);
+                            for (int k = 0; k < S.n_big; ++k) {   // scene-sized primitives kept out of the tree
+                                const int id = S.big[k];
+                                count_lanes(S, 7);
+                                if (id != skip) test_prim(S, id, o, d, maxd, best);
+                                if (ANY && best.prim >= 0) {
+                                    if (best.t < tlim) { found = true; break; }
+                                    best.prim = -1; best.t = INFINITY;
+                                }
+                            }
+                            node = 0; sp = 0; steps_left = 2 * S.n_prims + 8;
+                            if (found) have = false;
+                        }
+                        if (!have) {
+                            if (ANY) { if (found) atomicOr((unsigned*)&W.hits[entry].w, 1u << bit); }
+                            else W.hits[entry] = make_int4(__float_as_int(best.t), best.prim, best.aux, 0);
+                        }
+                    }
+                }
+                next += take;
+            }
+        }
+        if (!__any(have)) {
+            if (exhausted) break;
+            continue;
+        }
+        if (have) {
+            bool pop = true, finished = false, found = false;
+            if (node >= 0) {
+                count_lanes(S, 6);
+                const float4* n = S.bvh4 + 8 * (size_t)node;
+                const float4 lx = n[0], ly = n[1], lz = n[2], hx = n[3], hy = n[4], hz = n[5], cc = n[6];
+                const float lim = best.prim >= 0 ? best.t : lim0;
+                int c0 = __float_as_int(cc.x), c1 = __float_as_int(cc.y), c2 = __float_as_int(cc.z), c3 = __float_as_int(cc.w);
+                float t0, t1, t2, t3;
+                bool h0, h1, h2, h3;
+                {
+                    const v2f ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
+                    const v2f ix = {inv.x, inv.x}, iy = {inv.y, inv.y}, iz = {inv.z, inv.z};
+                    const v2f ax01 = (v2f{lx.x, lx.y} - ox) * ix, ax23 = (v2f{lx.z, lx.w} - ox) * ix;
+                    const v2f bx01 = (v2f{hx.x, hx.y} - ox) * ix, bx23 = (v2f{hx.z, hx.w} - ox) * ix;
+                    const v2f ay01 = (v2f{ly.x, ly.y} - oy) * iy, ay23 = (v2f{ly.z, ly.w} - oy) * iy;
+                    const v2f by01 = (v2f{hy.x, hy.y} - oy) * iy, by23 = (v2f{hy.z, hy.w} - oy) * iy;
+                    const v2f az01 = (v2f{lz.x, lz.y} - oz) * iz, az23 = (v2f{lz.z, lz.w} - oz) * iz;
+                    const v2f bz01 = (v2f{hz.x, hz.y} - oz) * iz, bz23 = (v2f{hz.z, hz.w} - oz) * iz;
+#define VRT_SLAB4(T, H, AX, BX, AY, BY, AZ, BZ)                                                       \
+                    {                                                                                 \
+                        float n_ = fmaxf(fmaxf(fminf(AX, BX), fminf(AY, BY)), fmaxf(fminf(AZ, BZ), 0.f)); \
+                        float f_ = fminf(fminf(fmaxf(AX, BX), fmaxf(AY, BY)), fminf(fmaxf(AZ, BZ), lim)); \
+                        T = n_; H = n_ <= f_ * 1.0000004f;                                            \
+                    }
+                    VRT_SLAB4(t0, h0, ax01.x, bx01.x, ay01.x, by01.x, az01.x, bz01.x)
+                    VRT_SLAB4(t1, h1, ax01.y, bx01.y, ay01.y, by01.y, az01.y, bz01.y)
+                    VRT_SLAB4(t2, h2, ax23.x, bx23.x, ay23.x, by23.x, az23.x, bz23.x)
+                    VRT_SLAB4(t3, h3, ax23.y, bx23.y, ay23.y, by23.y, az23.y, bz23.y)
+#undef VRT_SLAB4
+                }
+#define VRT_PUSH4(T, C)                                                                              \
+                {                                                                                    \
+                    unsigned long long e_ = ((unsigned long long)__float_as_uint(T) << 32) | (unsigned)(C); \
+                    if (sp < VRT_WF_TRACE_LDS) my_lds[sp * 256] = e_;                                  \
+                    else if (sp < VRT_BVH4_STACK) deep[sp - VRT_WF_TRACE_LDS] = e_;                    \
+                    sp++;                                                                            \
+                }
+                if (ANY) {
+                    bool taken = false;
+#define VRT_VISIT_ANY(H, C) if (H) { if (!taken) { node = C; taken = true; } else VRT_PUSH4(0.f, C) }
+                    VRT_VISIT_ANY(h0, c0) VRT_VISIT_ANY(h1, c1) VRT_VISIT_ANY(h2, c2) VRT_VISIT_ANY(h3, c3)
+#undef VRT_VISIT_ANY
+                    pop = !taken;
+                } else {
+                    t0 = h0 ? t0 : INFINITY;
+                    t1 = h1 ? t1 : INFINITY;
+                    t2 = h2 ? t2 : INFINITY;
+                    t3 = h3 ? t3 : INFINITY;
+                    order2(t0, c0, t1, c1); order2(t2, c2, t3, c3);
+                    order2(t0, c0, t2, c2); order2(t1, c1, t3, c3);
+                    order2(t1, c1, t2, c2);
+                    if (t0 < INFINITY) {
+                        node = c0;
+                        pop = false;
+                        if (t3 < INFINITY) VRT_PUSH4(t3, c3)
+                        if (t2 < INFINITY) VRT_PUSH4(t2, c2)
+                        if (t1 < INFINITY) VRT_PUSH4(t1, c1)
+                    }
+                }
+#undef VRT_PUSH4
+            } else {
+                const int id = ~node;
+                count_lanes(S, 7);
+                if (id != skip) test_prim(S, id, o, d, maxd, best);
+                if (ANY && best.prim >= 0) {
+                    if (best.t < tlim) found = finished = true;
+                    else { best.prim = -1; best.t = INFINITY; }
+                }
+            }
+            if (!finished && pop) {
+                const float lim = best.prim >= 0 ? best.t : lim0;
+                for (;;) {
+                    if (sp == 0) { finished = true; break; }
+                    --sp;
+                    unsigned long long e = sp < VRT_WF_TRACE_LDS ? my_lds[sp * 256]
+                                                              : deep[(sp < VRT_BVH4_STACK ? sp : VRT_BVH4_STACK - 1) - VRT_WF_TRACE_LDS];
+                    if (!(__uint_as_float((unsigned)(e >> 32)) > lim)) { node = (int)(unsigned)e; break; }
+                }
+            }
+            if (--steps_left <= 0) finished = true;   // only with a corrupt tree
+            if (finished) {
+                if (ANY) { if (found) atomicOr((unsigned*)&W.hits[entry].w, 1u << bit); }
+                else W.hits[entry] = make_int4(__float_as_int(best.t), best.prim, best.aux, 0);
+                have = false;
+            }
+        }
     }
 }
 
@@ -456,12 +667,17 @@ hipError_t run(const DevScene& S, const DevCam& cam, const DevParams& P, const W
         size_t live = (size_t)rows * per_row * (TWOCHILD ? 2 : 1);
         int bounce_blocks = (int)((live + 255) / 256 < VRT_WF_MAX_BLOCKS ? (live + 255) / 256 : VRT_WF_MAX_BLOCKS);
         if (W.hits) {
-            e = hipMemsetAsync(W.any_counts, 0, (VRT_MAX_DEPTH + 2) * sizeof(int), stream);
+            e = hipMemsetAsync(W.any_counts, 0, 3 * (VRT_MAX_DEPTH + 2) * sizeof(int), stream);   // counts and both cursors
             if (e != hipSuccess) return e;
         }
         for (int d = 1; d <= P.max_depth; ++d) {
-            if (W.hits) {
-                hipLaunchKernelGGL((k_wf_bounce_a<BVH>), dim3(bounce_blocks), dim3(256), 0, stream, S, P, W, d, ctr);
+            if (W.hits && BVH && W.refill) {
+                hipLaunchKernelGGL((k_wf_trace<false>), dim3(bounce_blocks), dim3(256), 0, stream, S, P, W, d);
+                hipLaunchKernelGGL((k_wf_bounce_a<BVH, true>), dim3(bounce_blocks), dim3(256), 0, stream, S, P, W, d, ctr);
+                hipLaunchKernelGGL((k_wf_trace<true>), dim3(bounce_blocks), dim3(256), 0, stream, S, P, W, d);
+                hipLaunchKernelGGL((k_wf_bounce_b<BVH, TWOCHILD>), dim3(bounce_blocks), dim3(256), 0, stream, S, P, W, d);
+            } else if (W.hits) {
+                hipLaunchKernelGGL((k_wf_bounce_a<BVH, false>), dim3(bounce_blocks), dim3(256), 0, stream, S, P, W, d, ctr);
                 hipLaunchKernelGGL((k_wf_any<BVH>), dim3(bounce_blocks), dim3(256), 0, stream, S, W, d);
                 hipLaunchKernelGGL((k_wf_bounce_b<BVH, TWOCHILD>), dim3(bounce_blocks), dim3(256), 0, stream, S, P, W, d);
             } else {
