@@ -6,9 +6,10 @@
 A step = one frame of the workload rendered by libvrt with camera/scene resident on the GPU
 and the framebuffer left in HBM.  At N = 1 the default workload is the teaching scene at
 1920x1080, 1 spp, reflection depth 5.  With N > 1 (one process per GPU under
-torch.distributed.run) the frame grows with N (same scene and camera, N times the pixels),
-is cut into 8-row strips dealt round-robin to the ranks, and the strips are gathered to rank 0
-with RCCL and de-interleaved there: per-GPU work is fixed, i.e. weak scaling.
+torch.distributed.run) the same 1920x1080 frame is rendered with N samples per pixel, cut into
+8-row strips dealt round-robin to the ranks (a rank renders all samples of its pixels), and
+the strips are gathered to rank 0 with RCCL and de-interleaved there: the rays per GPU are
+those of the one-GPU frame, i.e. weak scaling.
 
 Rank 0 prints one JSON line.  `value` is Mrays/s over all GPUs, a ray being one intersection
 query (primary + reflection + transmission + shadow + ambient-occlusion; the reference's
@@ -30,22 +31,28 @@ import torch.distributed as dist  # noqa: E402
 import raytracing_amd as ra  # noqa: E402
 from raytracing_amd import abi, host, tiles  # noqa: E402
 
-# Frame per world size: ~N x the pixels of 1920x1080, 16:9, height a multiple of 8*N rows.
-FRAMES = {1: (1920, 1080), 2: (2720, 1520), 4: (3840, 2176), 8: (5440, 3072)}
 PEAK_FP32_TFLOPS = 157.3   # MI355X vector FP32 (MI355X_MICROARCH.md, chip-level parameters)
 PEAK_HBM_GBPS = 8000.0
 
 
 def build_workload(name, n_gpus):
     if name == "c2":
-        w, h = FRAMES.get(n_gpus, (1920, 1080 * n_gpus))
+        # The frame stays 1920x1080 at every world size; N GPUs render N samples per pixel, so
+        # the rays per GPU stay those of the one-GPU frame (weak scaling) while a rank's share
+        # of the frame gather shrinks to 1/N of the 33 MB frame.  (Growing the pixel count with
+        # N instead leaves every rank a 33 MB message for its one xGMI link to rank 0 per
+        # 0.15 ms of rendering: the link, not the GPUs, would be what is measured.)
+        w, h = (1920, 1080)
         scene = ra.teaching_scene()
-        # keep the field of view of the 16:9 frame whatever the pixel count
         cam = ra.make_camera((1.45, 2.0, 2.5), (3.0, 1.55, 2.5 + (16 / 9) / 2), (0.0, 0.0, -16 / 9),
                              (0.0, 1.0, 0.0), w, h)
-        kw = dict(spp=1, max_depth=5, rng=30.0)
-        label = f"teaching scene {w}x{h}, 1 spp, depth 5"
+        spp = max(n_gpus, 1)
+        kw = dict(spp=spp, max_depth=5, rng=30.0)
+        label = f"teaching scene {w}x{h}, {spp} spp{' jittered' if spp > 1 else ''}, depth 5"
         offsets = None
+        if spp > 1:
+            offsets = host.sampler_table(abi.VRT_SAMPLER_JITTERED, spp, 83, (16 / 9) / w, 1.0 / h, seed=1)
+            kw["seed"] = 1
     elif name == "c3":
         w, h = (3840, 2160)
         scene = ra.random_spheres_scene(10000)
