@@ -507,7 +507,7 @@ static int prepare(vrt_ctx* c, const vrt_params* p, DevParams* out)
 // deferred occlusion queries (queues twice that with two children per hit); a frame with fewer samples gets a workspace of its own size.
 static const size_t kWfMaxSlots = 64ull << 20;
 
-static int ensure_wf(vrt_ctx* c, size_t slots, bool two)
+static int ensure_wf(vrt_ctx* c, size_t slots, bool two, hipStream_t stream)
 {
     // VRT_WF_DEFER=0 (study, tests): occlusion queries of the bounces traced where they arise
     const char* e = getenv("VRT_WF_DEFER");
@@ -524,7 +524,7 @@ static int ensure_wf(vrt_ctx* c, size_t slots, bool two)
         q.tr = b + 6 * cap; q.tg = b + 7 * cap; q.tb = b + 8 * cap;
         q.lr = b + 9 * cap; q.lg = b + 10 * cap; q.lb = b + 11 * cap;
         q.pix = (int*)(b + 12 * cap); q.skip = (int*)(b + 13 * cap); q.meta = (int*)(b + 14 * cap);
-        HIPCHK(c, hipMemset(q.pix, 0xff, cap * sizeof(int)));   // "unwritten" marks; consumers put them back
+        HIPCHK(c, hipMemsetAsync(q.pix, 0xff, cap * sizeof(int), stream));   // "unwritten" marks; consumers put them back
     }
     c->wf.cap = cap;
     HIPCHK(c, hipMalloc(&c->wf.lacc, slots * sizeof(float4)));
@@ -539,7 +539,7 @@ static int ensure_wf(vrt_ctx* c, size_t slots, bool two)
         a.ox = b; a.oy = b + cap; a.oz = b + 2 * cap; a.dx = b + 3 * cap; a.dy = b + 4 * cap; a.dz = b + 5 * cap;
         a.tlim = b + 6 * cap; a.maxd = b + 7 * cap;
         a.skip = (int*)(b + 8 * cap); a.target = (int*)(b + 9 * cap); a.bit = (int*)(b + 10 * cap);
-        HIPCHK(c, hipMemset(a.target, 0xff, cap * sizeof(int)));
+        HIPCHK(c, hipMemsetAsync(a.target, 0xff, cap * sizeof(int), stream));
         c->wf.any_cap = cap;
         if (const char* v = getenv("VRT_WF_ANY_CAP")) {   // tests: a short queue forces the in-place path
             long long n = atoll(v);
@@ -568,7 +568,7 @@ static int enqueue_frame(vrt_ctx* c, const vrt_params* p, const DevParams& P, fl
         if (want > max_slots) want = max_slots > min_band ? max_slots : min_band;
         if (want < min_band) want = min_band;
         if (want * (two ? 2 : 1) + 2 * VRT_WF_SLACK > 0x7fffffffull) return fail(c, VRT_ERR_CAPACITY, "frame row too long for the wavefront queues");
-        int rc = ensure_wf(c, want, two);
+        int rc = ensure_wf(c, want, two, stream);   // its fills run on the frame's stream, ahead of the kernels
         if (rc) return rc;
         WfWorkspace wf = c->wf;
         wf.slots = want; // a workspace kept from a larger frame still runs this frame in bands of `want`
