@@ -383,6 +383,9 @@ __device__ __forceinline__ Hit intersect_bvh(const DevScene& S, f3 o, f3 d, floa
 #ifndef VRT_LDS_TOP
 #define VRT_LDS_TOP 0
 #endif
+#ifndef VRT_SIGN_SLAB
+#define VRT_SIGN_SLAB 0
+#endif
 #if VRT_LDS_TOP
 __shared__ float4 g_lds_top[8 * VRT_TOP_NODES];
 __device__ __forceinline__ void stage_bvh_top(const DevScene& S)
@@ -430,6 +433,14 @@ __device__ __forceinline__ Hit intersect_bvh4(const DevScene& S, f3 o, f3 d, flo
     if (is_zero3(d)) return best;
     const f3 inv = mk3(1.f / d.x, 1.f / d.y, 1.f / d.z);
     const float lim0 = fminf(maxd, tlim);
+#if VRT_SIGN_SLAB
+    // Rows of a node that hold this ray's entry and exit plane per axis (rows 0..2 = lo.xyz,
+    // 3..5 = hi.xyz): with a negative direction component the ray enters through hi.  For
+    // finite products (plane - o) * inv is monotonic in the plane, so these are exactly the
+    // min and max of the two products the unordered test forms; a NaN product (0 * inf) is
+    // dropped by the min/max over the axes on one side only, which keeps more candidates, never fewer.
+    const int rnx = inv.x < 0.f ? 3 : 0, rny = inv.y < 0.f ? 4 : 1, rnz = inv.z < 0.f ? 5 : 2;
+#endif
     for (int k = 0; k < S.n_big; ++k) {   // scene-sized primitives kept out of the tree
         const int id = S.big[k];
         count_lanes(S, 7);
@@ -462,7 +473,11 @@ __device__ __forceinline__ Hit intersect_bvh4(const DevScene& S, f3 o, f3 d, flo
 #endif
             {
                 const float4* n = S.bvh4 + 8 * (size_t)node;
+#if VRT_SIGN_SLAB
+                lx = n[rnx]; ly = n[rny]; lz = n[rnz]; hx = n[rnx ^ 3]; hy = n[rny ^ 5]; hz = n[rnz ^ 7]; cc = n[6];
+#else
                 lx = n[0]; ly = n[1]; lz = n[2]; hx = n[3]; hy = n[4]; hz = n[5]; cc = n[6];
+#endif
             }
             const float lim = best.prim >= 0 ? best.t : lim0;
             int c0 = __float_as_int(cc.x), c1 = __float_as_int(cc.y), c2 = __float_as_int(cc.z), c3 = __float_as_int(cc.w);
@@ -477,12 +492,21 @@ __device__ __forceinline__ Hit intersect_bvh4(const DevScene& S, f3 o, f3 d, flo
                 const v2f by01 = (v2f{hy.x, hy.y} - oy) * iy, by23 = (v2f{hy.z, hy.w} - oy) * iy;
                 const v2f az01 = (v2f{lz.x, lz.y} - oz) * iz, az23 = (v2f{lz.z, lz.w} - oz) * iz;
                 const v2f bz01 = (v2f{hz.x, hz.y} - oz) * iz, bz23 = (v2f{hz.z, hz.w} - oz) * iz;
+#if VRT_SIGN_SLAB   // A* = entry side, B* = exit side
+#define VRT_SLAB4(T, H, AX, BX, AY, BY, AZ, BZ)                                                       \
+                {                                                                                     \
+                    float n_ = fmaxf(fmaxf(AX, AY), fmaxf(AZ, 0.f));                                  \
+                    float f_ = fminf(fminf(BX, BY), fminf(BZ, lim));                                  \
+                    T = n_; H = n_ <= f_ * 1.0000004f;                                                \
+                }
+#else
 #define VRT_SLAB4(T, H, AX, BX, AY, BY, AZ, BZ)                                                       \
                 {                                                                                     \
                     float n_ = fmaxf(fmaxf(fminf(AX, BX), fminf(AY, BY)), fmaxf(fminf(AZ, BZ), 0.f)); \
                     float f_ = fminf(fminf(fmaxf(AX, BX), fmaxf(AY, BY)), fminf(fmaxf(AZ, BZ), lim)); \
                     T = n_; H = n_ <= f_ * 1.0000004f;                                                \
                 }
+#endif
                 VRT_SLAB4(t0, h0, ax01.x, bx01.x, ay01.x, by01.x, az01.x, bz01.x)
                 VRT_SLAB4(t1, h1, ax01.y, bx01.y, ay01.y, by01.y, az01.y, bz01.y)
                 VRT_SLAB4(t2, h2, ax23.x, bx23.x, ay23.x, by23.x, az23.x, bz23.x)
