@@ -625,20 +625,35 @@ __global__ __launch_bounds__(256, VRT_WF_BOUNCE_BLOCKS) void k_wf_bounce_b(DevSc
     }
 }
 
+// Lanes = pixels x samples with the megakernel's split (P.sample_shift): every lane reads its
+// own slot, so a wave reads consecutive float4s, and lane 0 of each pixel's group adds the
+// group's radiances in sample order through wave shuffles (RayTracerUnity.cs:580-592).
 __global__ __launch_bounds__(256) void k_wf_resolve(DevCam cam, DevParams P, WfWorkspace W, int row0, int band_rows,
                                                     float4* __restrict__ rgba)
 {
-    int lp = blockIdx.x * 256 + threadIdx.x;
-    if (lp >= band_rows * cam.width) return;
-    int rb = lp / cam.width, v = lp % cam.width;
-    int r = row0 + rb;
-    int h = local_to_global_row(P, r);
-    if (r >= P.local_rows || h >= cam.height) return;
-    const float4* a = W.lacc + (size_t)lp * P.spp;
+    const int shift = P.sample_shift, n_sl = 1 << shift;
+    const int lane = threadIdx.x & 63, si = lane & (n_sl - 1);
+    const long long lp = ((long long)blockIdx.x * 256 + threadIdx.x) >> shift;   // pixel of the band
+    const bool inside = lp < (long long)band_rows * cam.width;
+    const int rb = inside ? (int)(lp / cam.width) : 0, v = inside ? (int)(lp % cam.width) : 0;
+    const int r = row0 + rb;
+    const int h = local_to_global_row(P, r);
+    const bool live = inside && r < P.local_rows && h < cam.height;
+    const float4* a = W.lacc + (size_t)(inside ? lp : 0) * P.spp;
     f3 sum = mk3(0.f, 0.f, 0.f);
-    for (int i = 0; i < P.spp; ++i) { float4 q = a[i]; sum = sum + mk3(q.x, q.y, q.z); }
-    f3 fin = sum / (float)P.spp;
-    rgba[(size_t)(P.compact ? r : h) * cam.width + v] = process_color(fin);
+    for (int base = 0; base < P.spp; base += n_sl) {   // wave-uniform trip count
+        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (live && base + si < P.spp) q = a[base + si];
+        for (int k = 0; k < n_sl; ++k) {
+            const int src = (lane & ~(n_sl - 1)) + k;
+            const float x = __shfl(q.x, src, 64), y = __shfl(q.y, src, 64), z = __shfl(q.z, src, 64);
+            if (base + k < P.spp) sum = sum + mk3(x, y, z);
+        }
+    }
+    if (live && si == 0) {
+        f3 fin = sum / (float)P.spp;
+        rgba[(size_t)(P.compact ? r : h) * cam.width + v] = process_color(fin);
+    }
 }
 
 template <bool BVH, bool TWOCHILD>
@@ -684,7 +699,7 @@ hipError_t run(const DevScene& S, const DevCam& cam, const DevParams& P, const W
                 hipLaunchKernelGGL((k_wf_bounce<BVH, TWOCHILD>), dim3(bounce_blocks), dim3(256), 0, stream, S, P, W, d, ctr);
             }
         }
-        hipLaunchKernelGGL(k_wf_resolve, dim3((unsigned)(((size_t)rows * cam.width + 255) / 256)), dim3(256), 0, stream,
+        hipLaunchKernelGGL(k_wf_resolve, dim3((unsigned)((((size_t)rows * cam.width << P.sample_shift) + 255) / 256)), dim3(256), 0, stream,
                            cam, P, W, row0, rows, rgba);
     }
     return hipGetLastError();
