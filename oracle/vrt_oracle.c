@@ -303,7 +303,9 @@ static int slab(const bnode* n, oray r, const float inv[3], float tmax)
 }
 
 /* Closest hit (any = 0) or "is there any hit" (any = 1) within maxd, ignoring primitive
- * `skip` (the primitive a secondary ray was spawned on: see DESIGN.md, intersection rules). */
+ * `skip`, the primitive a secondary ray was spawned on: PhysX raycasts that start on a collider's
+ * surface do not report that collider (the ray begins touching or just inside it), which is what
+ * keeps the reference's shadow, occlusion and reflection rays from hitting their own origin. */
 static ohit intersect(const oscene* s, oray r, float maxd, int skip, int any)
 {
     ohit best; memset(&best, 0, sizeof best); best.prim = -1;
