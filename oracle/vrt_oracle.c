@@ -303,9 +303,10 @@ static int slab(const bnode* n, oray r, const float inv[3], float tmax)
 }
 
 /* Closest hit (any = 0) or "is there any hit" (any = 1) within maxd, ignoring primitive
- * `skip`, the primitive a secondary ray was spawned on: PhysX raycasts that start on a collider's
- * surface do not report that collider (the ray begins touching or just inside it), which is what
- * keeps the reference's shadow, occlusion and reflection rays from hitting their own origin. */
+ * `skip`, the primitive a secondary ray was spawned on.  The reference starts those rays exactly
+ * on the surface, without an epsilon: an outward ray cannot re-hit a convex collider, and for an
+ * inward one Unity does not report a collider that contains the origin, so the source is never
+ * the answer; naming it here replaces PhysX's behaviour at t ~ 0, which is rounding noise. */
 static ohit intersect(const oscene* s, oray r, float maxd, int skip, int any)
 {
     ohit best; memset(&best, 0, sizeof best); best.prim = -1;
