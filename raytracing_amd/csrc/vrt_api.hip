@@ -274,6 +274,10 @@ extern "C" int vrt_set_scene(vrt_ctx* c, const vrt_scene_desc* d)
         pm[d->n_spheres + d->n_boxes + i] = m;
     }
 
+    for (uint32_t i = 0; i < d->n_lights; ++i)   // everything is validated before the old scene is dropped
+        if (d->lights[i].type != VRT_LIGHT_DIRECTIONAL && d->lights[i].type != VRT_LIGHT_POINT)
+            return fail(c, VRT_ERR_INVALID, "bad light type");
+
     // textures (Tracer/WhittedTracer.cs:55-63)
     std::vector<int> mat_tex;
     std::vector<int4> tex_info;
@@ -335,7 +339,6 @@ extern "C" int vrt_set_scene(vrt_ctx* c, const vrt_scene_desc* d)
     memset(lights.data(), 0, lights.size() * sizeof(DevLight));
     for (uint32_t i = 0; i < d->n_lights; ++i) {
         const vrt_light& l = d->lights[i];
-        if (l.type != VRT_LIGHT_DIRECTIONAL && l.type != VRT_LIGHT_POINT) return fail(c, VRT_ERR_INVALID, "bad light type");
         DevLight& o = lights[i];
         o.type = l.type; o.vx = l.vec[0]; o.vy = l.vec[1]; o.vz = l.vec[2]; o.ls = l.ls;
         o.cr = l.color[0]; o.cg = l.color[1]; o.cb = l.color[2]; o.cast = l.cast_shadows;

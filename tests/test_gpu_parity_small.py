@@ -111,6 +111,15 @@ def test_error_paths(vrt_ctx):
     bad.spheres["material"][0] = 99
     with pytest.raises(host.VrtError):
         vrt_ctx.set_scene(bad)
+    # a rejected scene leaves the one before it in place
+    before, _, _ = vrt_ctx.render(ra.Params(spp=1))
+    bad = ra.teaching_scene()
+    bad.lights["type"][0] = 7
+    with pytest.raises(host.VrtError) as e:
+        vrt_ctx.set_scene(bad)
+    assert e.value.code == abi.VRT_ERR_INVALID
+    after, _, _ = vrt_ctx.render(ra.Params(spp=1))
+    assert np.array_equal(before, after, equal_nan=True)
     vrt_ctx.set_scene(scene)
 
 
