@@ -265,15 +265,24 @@ def main():
         # to the other ranks before each uploads it to its own GPU
         scene = tiles.broadcast_scene(scene if rank == 0 else ra.Scene(), cdev)
     mode = {"auto": abi.VRT_MODE_AUTO, "mega": abi.VRT_MODE_MEGAKERNEL, "wavefront": abi.VRT_MODE_WAVEFRONT}[args.mode]
+    # With more than one GPU the strips travel as 3 floats per pixel, the averaged radiance before
+    # tone mapping (12 instead of 16 bytes per pixel over a rank's one xGMI link to rank 0), and
+    # rank 0 tone-maps the gathered frame: the same arithmetic on the same values, one step later.
+    linear = world > 1
+    prm_kw = dict(kw, flags=kw.get("flags", 0) | abi.VRT_OUT_LINEAR_RGB) if linear else kw
     prm = ra.Params(offsets=offsets, mode=mode, tile_index=rank, tile_count=world, tile_rows=args.tile_rows,
-                    compact_rows=True, **kw)
+                    compact_rows=True, **prm_kw)
     ctx = host.Context(local_rank)
     ctx.set_scene(scene)
     ctx.set_camera(cam)
 
     W, H = cam.width, cam.height
     # two frame buffers: while frame k is being gathered (RCCL, its own stream) frame k+1 renders
-    fgs = [tiles.FrameGather(H, W, 4, world, rank, args.tile_rows, cdev) for _ in range(2 if world > 1 else 1)]
+    fgs = [tiles.FrameGather(H, W, 3 if linear else 4, world, rank, args.tile_rows, cdev)
+           for _ in range(2 if world > 1 else 1)]
+    frames_rgba = [torch.empty((H, W, 4), dtype=torch.float32, device=dev) if (linear and rank == 0) else None
+                   for _ in fgs]
+    staged = [None] * len(fgs)
     fg = fgs[0]
     local = fg.local if not rehearsal else torch.empty_like(fg.local, device=dev)
     local_hit = torch.empty((fg.rows_max, W), dtype=torch.int32, device=dev)
@@ -281,12 +290,19 @@ def main():
     pending = [None, None]
     frame_no = [0]
 
+    def finish(k):
+        # wait for the gather of the frame in buffer k, de-interleave and tone-map it on rank 0
+        fgs[k].finish(pending[k])
+        pending[k] = None
+        if frames_rgba[k] is not None:
+            staged[k] = fgs[k].final if not rehearsal else fgs[k].final.to(dev)
+            ctx.tonemap_device(staged[k].data_ptr(), frames_rgba[k].data_ptr(), H * W, stream.cuda_stream)
+
     def step():
         k = frame_no[0] % len(fgs)
         frame_no[0] += 1
         if world > 1 and pending[k] is not None:
-            fgs[k].finish(pending[k])  # frame k-2: wait for its gather, de-interleave on rank 0
-            pending[k] = None
+            finish(k)  # the frame rendered two steps ago
         target = local if rehearsal else fgs[k].local
         ctx.render_device(prm, target.data_ptr(), local_hit.data_ptr(), stream.cuda_stream)
         if rehearsal:
@@ -297,8 +313,7 @@ def main():
     def drain():
         for k in range(len(fgs)):
             if pending[k] is not None:
-                fgs[k].finish(pending[k])
-                pending[k] = None
+                finish(k)
 
     for _ in range(args.warmup):
         step()
@@ -315,7 +330,7 @@ def main():
             wp = ra.Params(offsets=offsets, mode=mode, **kw)
             ctx.render_device(wp, whole.data_ptr(), None, stream.cuda_stream)
             torch.cuda.synchronize()
-            got = fgs[(frame_no[0] - 1) % len(fgs)].final.to(dev)
+            got = frames_rgba[(frame_no[0] - 1) % len(fgs)]
             frames_match = bool(torch.equal(torch.nan_to_num(got), torch.nan_to_num(whole)))
             del whole, got
         ctx.render_device(prm, (local if rehearsal else fgs[0].local).data_ptr(), local_hit.data_ptr(), stream.cuda_stream)
@@ -403,7 +418,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": label, "frame": [W, H], "rays_per_frame": queries,
                        "mode": "wavefront" if st.mode_used == abi.VRT_MODE_WAVEFRONT else "megakernel",
-                       "gather": "rccl gather to rank 0, overlapped with the next frame" if world > 1 else "none",
+                       "gather": "rccl gather of 3-float radiance strips to rank 0, tone mapping after the gather, "
+                                 "overlapped with the next frame" if world > 1 else "none",
                        "scene": "broadcast from rank 0" if world > 1 else "local",
                        "rays_by_class": {n: int(r) for n, r in zip(abi.RAY_CLASS_NAMES, rays)}},
             "ms_per_frame_kernel": kernel_ms,

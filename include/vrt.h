@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define VRT_ABI_VERSION 3
+#define VRT_ABI_VERSION 4
 
 typedef struct vrt_ctx vrt_ctx;
 
@@ -60,9 +60,14 @@ enum {
     VRT_FIX_AO_BASIS = 1u << 1,    /* ambient-occlusion ray always leaves along the normal; the
                                       reference poisons it with NaN for most normals
                                       (Light/AmbientOccluder.cs:66-73) */
-    VRT_FIX_DIELECTRIC = 1u << 2   /* Fresnel reflection + refraction with EtaIn/EtaOut instead
+    VRT_FIX_DIELECTRIC = 1u << 2,  /* Fresnel reflection + refraction with EtaIn/EtaOut instead
                                       of the always-total-internal-reflection wiring
                                       (Material/DielectricMaterial.cs:73, BTDF/FresnelTransmitterBTDF.cs:57-69) */
+    /* Not a behaviour switch: output format of vrt_render_device only.  The frame buffer receives
+       3 floats per pixel, the averaged radiance BEFORE MaxToOne (Util/RayTraceUtility.cs:409-422);
+       vrt_tonemap_device turns it into the usual 4 floats.  Multi-GPU hosts gather strips in
+       this form (12 instead of 16 bytes per pixel over xGMI) and tone-map once, after the gather. */
+    VRT_OUT_LINEAR_RGB = 1u << 8
 };
 
 /* Kernel organisation. */
@@ -197,7 +202,7 @@ typedef struct vrt_params {
     uint32_t seed;        /* selects the set per pixel: set = vrt_pixel_set(seed, pixel, n_sets) */
     int32_t max_depth;    /* GlobalWorld.MaxDepth */
     float range;          /* RayTrace_Range */
-    uint32_t flags;       /* VRT_FIX_* */
+    uint32_t flags;       /* VRT_FIX_* | VRT_OUT_* */
     int32_t mode;         /* VRT_MODE_* */
     /* Tile sharding: the frame is cut into strips of tile_rows rows; this call renders
      * strips s with s % tile_count == tile_index and leaves the other rows untouched. */
@@ -270,6 +275,12 @@ int vrt_render_end(vrt_ctx* ctx, vrt_stats* stats_out);
 int vrt_render_device(vrt_ctx* ctx, const vrt_params* params, void* rgba_dev,
                       void* hit_id_dev, void* stream);
 int vrt_fetch_stats(vrt_ctx* ctx, vrt_stats* stats_out);
+
+/* RayTracerUnity.ProcessColor (RayTracerUnity.cs:525-562) for n_pixels pixels already in device
+ * memory: rgb_dev holds 3 floats per pixel as VRT_OUT_LINEAR_RGB leaves them, rgba_dev receives
+ * 4 floats per pixel, bit for bit what the frame kernel writes without that flag.  Enqueues on
+ * `stream` (a hipStream_t or NULL) and returns. */
+int vrt_tonemap_device(vrt_ctx* ctx, const void* rgb_dev, void* rgba_dev, uint64_t n_pixels, void* stream);
 
 /* Single-step VR mode: one pixel, optionally one sample (sample < 0 = all samples,
  * averaged and tone-mapped like a frame pixel).  Replaces one DoRayTraceArchitecture

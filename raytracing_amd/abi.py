@@ -5,7 +5,7 @@ test-side oracle binding can share the data formats.
 """
 import ctypes as C
 
-VRT_ABI_VERSION = 3
+VRT_ABI_VERSION = 4
 
 VRT_OK = 0
 VRT_ERR_INVALID = -1
@@ -19,6 +19,7 @@ VRT_LIGHT_DIRECTIONAL, VRT_LIGHT_POINT = 0, 1
 (VRT_SAMPLER_REGULAR, VRT_SAMPLER_RANDOM, VRT_SAMPLER_JITTERED, VRT_SAMPLER_NROOKS,
  VRT_SAMPLER_MULTIJITTERED, VRT_SAMPLER_HAMMERSLEY) = range(6)
 VRT_FIX_PRIMARY_SKY, VRT_FIX_AO_BASIS, VRT_FIX_DIELECTRIC = 1, 2, 4
+VRT_OUT_LINEAR_RGB = 1 << 8
 VRT_MODE_AUTO, VRT_MODE_MEGAKERNEL, VRT_MODE_WAVEFRONT = 0, 1, 2
 (VRT_RAY_PRECHECK, VRT_RAY_PRIMARY, VRT_RAY_REFLECT, VRT_RAY_TRANSMIT, VRT_RAY_SHADOW,
  VRT_RAY_AO) = range(6)
@@ -110,6 +111,6 @@ class vrt_stats(C.Structure):
 EXPORTS = (
     "vrt_create", "vrt_destroy", "vrt_last_error", "vrt_shading_defaults",
     "vrt_params_defaults", "vrt_set_scene", "vrt_set_camera", "vrt_render",
-    "vrt_render_begin", "vrt_render_poll", "vrt_render_end", "vrt_render_device", "vrt_fetch_stats", "vrt_trace_pixel", "vrt_trace_ray", "vrt_sampler_table",
+    "vrt_render_begin", "vrt_render_poll", "vrt_render_end", "vrt_render_device", "vrt_fetch_stats", "vrt_tonemap_device", "vrt_trace_pixel", "vrt_trace_ray", "vrt_sampler_table",
     "vrt_pixel_set", "vrt_abi_version",
 )

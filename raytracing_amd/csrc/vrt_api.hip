@@ -466,7 +466,8 @@ static int prepare(vrt_ctx* c, const vrt_params* p, DevParams* out)
     DevParams& P = *out;
     memset(&P, 0, sizeof P);
     P.spp = p->spp; P.n_sets = p->offsets ? p->n_sets : 1; P.seed = p->seed;
-    P.max_depth = p->max_depth; P.range = p->range; P.flags = p->flags;
+    P.max_depth = p->max_depth; P.range = p->range;
+    P.flags = p->flags & ~(unsigned)VRT_OUT_LINEAR_RGB;   // an output format only vrt_render_device offers
     P.tile_index = tcount > 1 ? p->tile_index : 0; P.tile_count = tcount;
     P.tile_rows = p->tile_rows > 0 ? p->tile_rows : 8;
     P.local_rows = owned_rows(c->cam.height, P.tile_index, tcount, P.tile_rows);
@@ -662,6 +663,7 @@ static int run_records(vrt_ctx* c, const vrt_params* p, const DevParams& P, cons
 static int begin_frame(vrt_ctx* c, const vrt_params* p, float* rgba_out, int32_t* hit_id_out, DevParams* P_out)
 {
     if (c->pending) return fail(c, VRT_ERR_STATE, "a frame started with vrt_render_begin is still in flight");
+    if (p->flags & VRT_OUT_LINEAR_RGB) return fail(c, VRT_ERR_INVALID, "VRT_OUT_LINEAR_RGB is an output format of vrt_render_device");
     HIPCHK(c, hipSetDevice(c->device));
     DevParams& P = *P_out;
     int rc = prepare(c, p, &P);
@@ -753,7 +755,18 @@ extern "C" int vrt_render_device(vrt_ctx* c, const vrt_params* p, void* rgba_dev
     if (rc) return rc;
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     c->timed = false;
+    P.flags |= p->flags & VRT_OUT_LINEAR_RGB;
     return enqueue_frame(c, p, P, (float4*)rgba_dev, (int*)hit_id_dev, s);
+}
+
+extern "C" int vrt_tonemap_device(vrt_ctx* c, const void* rgb_dev, void* rgba_dev, uint64_t n_pixels, void* stream)
+{
+    if (!c || (n_pixels && (!rgb_dev || !rgba_dev))) return fail(c, VRT_ERR_INVALID, "null argument");
+    if (n_pixels > (1ull << 40)) return fail(c, VRT_ERR_INVALID, "pixel count out of range");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    HIPCHK(c, vrt_launch_tonemap((const float*)rgb_dev, (float4*)rgba_dev, (size_t)n_pixels, s));
+    return VRT_OK;
 }
 
 extern "C" int vrt_fetch_stats(vrt_ctx* c, vrt_stats* stats_out)

@@ -150,7 +150,12 @@ __global__ __launch_bounds__(VRT_MEGA_THREADS, BVH ? VRT_BVH_WAVES : (SIMPLE ? V
     if (inside && si == 0) {
         f3 fin = sum / (float)P.spp;
         size_t idx = (size_t)(P.compact ? r : h) * cam.width + v; // RayTracerUnity.cs:442
-        rgba[idx] = process_color(fin);
+        if (P.flags & VRT_OUT_LINEAR_RGB) {   // 3 floats per pixel, tone mapping left to vrt_tonemap_device
+            float* o = (float*)rgba + 3 * idx;
+            o[0] = fin.x; o[1] = fin.y; o[2] = fin.z;
+        } else {
+            rgba[idx] = process_color(fin);
+        }
         if (hit_id) hit_id[idx] = id;
     }
 #endif
@@ -278,5 +283,21 @@ hipError_t vrt_launch_ray(const DevScene& S, const DevParams& P, bool bvh, bool 
     if (bvh) { if (twochild) VRT_GO(true, true); else VRT_GO(true, false); }
     else     { if (twochild) VRT_GO(false, true); else VRT_GO(false, false); }
 #undef VRT_GO
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ tone mapping after a gather
+
+__global__ __launch_bounds__(256) void k_tonemap(const float* __restrict__ rgb, float4* __restrict__ rgba, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    rgba[i] = process_color(mk3(rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2]));
+}
+
+hipError_t vrt_launch_tonemap(const float* rgb, float4* rgba, size_t n, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_tonemap, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, rgb, rgba, n);
     return hipGetLastError();
 }

@@ -51,3 +51,6 @@ hipError_t vrt_launch_wavefront(const DevScene& S, const DevCam& cam, const DevP
 // nodes stay unwritten) and the 8*VRT_TOP_NODES float4 breadth-first top table to `top`.  Returns the binary tree depth in *depth_out.  Synchronises the stream.
 hipError_t vrt_build_lbvh(const DevScene& S, float4* nodes, float4* wide, float4* top, int* depth_out, float* ms_out,
                           hipStream_t stream);
+
+// process_color over n pixels: 3 floats in, 4 floats out.
+hipError_t vrt_launch_tonemap(const float* rgb, float4* rgba, size_t n, hipStream_t stream);

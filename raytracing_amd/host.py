@@ -60,6 +60,8 @@ def load_library():
     L.vrt_render_end.argtypes = [vp, C.POINTER(abi.vrt_stats)]
     L.vrt_render_device.restype = C.c_int
     L.vrt_render_device.argtypes = [vp, C.POINTER(abi.vrt_params), vp, vp, vp]
+    L.vrt_tonemap_device.restype = C.c_int
+    L.vrt_tonemap_device.argtypes = [vp, vp, vp, C.c_uint64, vp]
     L.vrt_fetch_stats.restype = C.c_int
     L.vrt_fetch_stats.argtypes = [vp, C.POINTER(abi.vrt_stats)]
     L.vrt_trace_pixel.restype = C.c_int
@@ -162,6 +164,10 @@ class Context:
         """Enqueues a frame whose outputs stay in device memory (raw device pointers)."""
         self._chk(self._lib.vrt_render_device(self._h, C.byref(params.c), rgba_ptr, hit_ptr,
                                               stream))
+
+    def tonemap_device(self, rgb_ptr, rgba_ptr, n_pixels, stream=None):
+        """3 floats per pixel as VRT_OUT_LINEAR_RGB leaves them -> the frame's 4 floats per pixel."""
+        self._chk(self._lib.vrt_tonemap_device(self._h, rgb_ptr, rgba_ptr, n_pixels, stream))
 
     def fetch_stats(self):
         st = abi.vrt_stats()

@@ -23,6 +23,11 @@ def oracle_mod():
 @pytest.fixture(scope="session")
 def vrt_ctx():
     """One context on GPU 0 for the whole GPU test session."""
+    # torch brings its own copy of the HIP runtime; tests that hand torch tensors to libvrt need
+    # torch's to come up first (the other order leaves torch without a device), as in bench.py
+    import torch
+    if torch.cuda.is_available():
+        torch.cuda.init()
     from raytracing_amd import host
     ctx = host.Context(0)
     yield ctx

@@ -176,3 +176,34 @@ def test_frames_do_not_depend_on_the_tree(vrt_ctx, which):
     for r in results[1:]:
         assert np.array_equal(r[0], results[0][0], equal_nan=True)
         assert np.array_equal(r[1], results[0][1]) and r[2] == results[0][2]
+
+
+@pytest.mark.parametrize("mode", [abi.VRT_MODE_MEGAKERNEL, abi.VRT_MODE_WAVEFRONT])
+def test_linear_rgb_output_then_tonemap_equals_frame(vrt_ctx, mode):
+    """VRT_OUT_LINEAR_RGB leaves 3 floats per pixel before tone mapping (what the strips of a
+    multi-GPU frame travel as); vrt_tonemap_device turns them into the frame's 4 floats, bit for bit."""
+    import torch
+    scene, cam = ra.teaching_scene(), ra.teaching_camera(160, 88)
+    vrt_ctx.set_scene(scene)
+    vrt_ctx.set_camera(cam)
+    offs = host.sampler_table(abi.VRT_SAMPLER_JITTERED, 4, 7, 0.01, 0.01, seed=2)
+    kw = dict(spp=4, offsets=offs, seed=3, max_depth=5, mode=mode)
+    want, _, _ = vrt_ctx.render(ra.Params(**kw))
+    assert (want[..., :3].max(axis=-1) == 1.0).any() and (want[..., 3] != 1.0).any()   # some pixels are tone-mapped
+    rgb = torch.full((88, 160, 3), -1.0, device="cuda")
+    out = torch.full((88, 160, 4), -1.0, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    vrt_ctx.render_device(ra.Params(flags=abi.VRT_OUT_LINEAR_RGB, **kw), rgb.data_ptr(), None, st)
+    vrt_ctx.tonemap_device(rgb.data_ptr(), out.data_ptr(), 88 * 160, st)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), want, equal_nan=True)
+    # strips, packed: the same rows
+    rows = [h for h in range(88) if (h // 8) % 2 == 1]
+    part = torch.zeros((len(rows), 160, 3), device="cuda")
+    vrt_ctx.render_device(ra.Params(flags=abi.VRT_OUT_LINEAR_RGB, tile_index=1, tile_count=2, tile_rows=8,
+                                    compact_rows=True, **kw), part.data_ptr(), None, st)
+    torch.cuda.synchronize()
+    assert torch.equal(torch.nan_to_num(part), torch.nan_to_num(rgb[rows]))
+    with pytest.raises(host.VrtError) as e:   # host-buffer frames are always 4 floats per pixel
+        vrt_ctx.render(ra.Params(flags=abi.VRT_OUT_LINEAR_RGB, **kw))
+    assert e.value.code == abi.VRT_ERR_INVALID
