@@ -13,7 +13,7 @@ public static class VrtNative
 {
     const string Lib = "vrt";
     const CallingConvention CC = CallingConvention.Cdecl;
-    public const int AbiVersion = 3;
+    public const int AbiVersion = 4;
 
     public const int MatSolid = 1, MatMetal = 2, MatDielectric = 3;         // RayTraceUtility.MaterialType
     public const int LightDirectional = 0, LightPoint = 1;
