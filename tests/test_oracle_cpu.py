@@ -215,3 +215,18 @@ def test_oracle_omp_equals_serial(oracle_mod):
     b = oracle_mod.render(scene, cam, prm.c, n_threads=4)
     assert np.array_equal(a[0], b[0], equal_nan=True) and np.array_equal(a[1], b[1])
     assert np.array_equal(a[2], b[2])
+
+
+def test_csharp_binding_agrees_with_the_header():
+    """The C# adapter cannot be compiled here; at least its ABI version, flag values and the entry
+    points it imports are those of include/vrt.h."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cs = open(os.path.join(root, "unity", "VrtNative.cs")).read()
+    hdr = open(os.path.join(root, "include", "vrt.h")).read()
+    assert int(re.search(r"AbiVersion\s*=\s*(\d+)", cs).group(1)) == int(re.search(r"#define VRT_ABI_VERSION (\d+)", hdr).group(1))
+    declared = set(re.findall(r"\b(vrt_[a-z_]+)\s*\(", hdr))
+    imported = set(re.findall(r"extern\s+\w+\s+(vrt_[a-z_]+)\s*\(", cs))
+    assert imported and imported <= declared, imported - declared
+    m = re.search(r"FixPrimarySky = (\d+), FixAoBasis = (\d+), FixDielectric = (\d+)", cs)
+    assert [int(x) for x in m.groups()] == [abi.VRT_FIX_PRIMARY_SKY, abi.VRT_FIX_AO_BASIS, abi.VRT_FIX_DIELECTRIC]
