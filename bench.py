@@ -290,13 +290,24 @@ def main():
     pending = [None, None]
     frame_no = [0]
 
+    # Assembling a gathered frame (de-interleave + tone mapping, ~60 MB of traffic on rank 0) runs on
+    # a stream of its own so that it overlaps rank 0's rendering instead of queueing behind it; the
+    # render stream only waits for the gather itself before it reuses a strip buffer.
+    side = torch.cuda.Stream(device=dev) if world > 1 else None
+    gathered_ev = [torch.cuda.Event() for _ in fgs]
+
     def finish(k):
         # wait for the gather of the frame in buffer k, de-interleave and tone-map it on rank 0
-        fgs[k].finish(pending[k])
-        pending[k] = None
-        if frames_rgba[k] is not None:
-            staged[k] = fgs[k].final if not rehearsal else fgs[k].final.to(dev)
-            ctx.tonemap_device(staged[k].data_ptr(), frames_rgba[k].data_ptr(), H * W, stream.cuda_stream)
+        with torch.cuda.stream(side):
+            handle, pending[k] = pending[k], None
+            handle.wait()
+            gathered_ev[k].record(side)
+            if rank == 0:
+                fgs[k].deinterleave()
+            if frames_rgba[k] is not None:
+                staged[k] = fgs[k].final if not rehearsal else fgs[k].final.to(dev)
+                ctx.tonemap_device(staged[k].data_ptr(), frames_rgba[k].data_ptr(), H * W, side.cuda_stream)
+        stream.wait_event(gathered_ev[k])
 
     def step():
         k = frame_no[0] % len(fgs)

@@ -90,6 +90,11 @@ class FrameGather:
             return self.final
         return None
 
+    def deinterleave(self):
+        """Rank 0, after the gather has completed on the current stream: strips -> row order.
+        For callers that wait for the gather themselves (e.g. on a stream of their own)."""
+        self._deinterleave()
+
     def _deinterleave(self):
         flat = self.gathered.view(self.world * self.rows_max, self.w, self.c)
         self._final_buf.index_copy_(0, self.dst_index, flat)
