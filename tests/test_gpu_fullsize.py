@@ -69,18 +69,28 @@ def test_c2_teaching_1080p(vrt_ctx, oracle_mod):
 
 def test_c3_ten_thousand_spheres_4k(vrt_ctx, oracle_mod):
     scene, cam = ra.random_spheres_scene(10000), ra.random_spheres_camera(3840, 2160)
-    offs = host.sampler_table(abi.VRT_SAMPLER_JITTERED, 4, 83, 2.4 * (16 / 9) / 3840, 2.4 / 2160, seed=1)
-    kw = dict(spp=4, max_depth=8, rng=200.0, seed=1)
+    offs = host.sampler_table(abi.VRT_SAMPLER_JITTERED, 16, 83, 2.4 * (16 / 9) / 3840, 2.4 / 2160, seed=1)
+    kw = dict(spp=16, max_depth=8, rng=200.0, seed=1)
     prm, rgba, hit, st = _properties(vrt_ctx, scene, cam, kw, offsets=offs)
     _sample_check(oracle_mod, scene, cam, prm, rgba, hit, n=1500)
     assert st.bvh_nodes == scene.n_prims - 1
 
 
+def test_c5_ten_thousand_spheres_8k_64spp(vrt_ctx, oracle_mod):
+    scene, cam = ra.random_spheres_scene(10000), ra.random_spheres_camera(7680, 4320)
+    offs = host.sampler_table(abi.VRT_SAMPLER_JITTERED, 64, 83, 2.4 * (16 / 9) / 7680, 2.4 / 4320, seed=1)
+    kw = dict(spp=64, max_depth=8, rng=200.0, seed=1)
+    prm, rgba, hit, st = _properties(vrt_ctx, scene, cam, kw, offsets=offs)
+    _sample_check(oracle_mod, scene, cam, prm, rgba, hit, n=400)
+    assert sum(st.rays[1:]) > 4_000_000_000
+
+
 def test_c4_million_triangles_1080p(vrt_ctx, oracle_mod):
     scene, cam = ra.tessellated_mesh_scene(708), ra.tessellated_mesh_camera(1920, 1080)
     assert len(scene.indices) >= 1_000_000
-    kw = dict(spp=1, max_depth=5, rng=100.0)
-    prm, rgba, hit, st = _properties(vrt_ctx, scene, cam, kw)
+    offs = host.sampler_table(abi.VRT_SAMPLER_JITTERED, 4, 83, 2.0 * (16 / 9) / 1920, 2.0 / 1080, seed=1)
+    kw = dict(spp=4, max_depth=5, rng=100.0, seed=1)
+    prm, rgba, hit, st = _properties(vrt_ctx, scene, cam, kw, offsets=offs)
     _sample_check(oracle_mod, scene, cam, prm, rgba, hit, n=1500)
 
 
