@@ -59,9 +59,10 @@ __device__ __forceinline__ void flush_counters(const Counters& C, unsigned long 
 // deepest path of each round.  The per-pixel sum is still formed in sample order
 // (RayTracerUnity.cs:580-592): the lanes' radiances are read back one by one with a wave shuffle.
 // One wave per block measured 6 % faster than four (finer-grained tail).
-// The BVH variant is capped at 96 VGPRs for 5 waves per SIMD (+18 % on 10k spheres, +8 % on 1M
-// triangles despite some spills; 6 and 8 waves spill too much).  The brute-force variant is
-// faster unconstrained (4 waves).
+// Every variant is compiled for 4 waves per SIMD (128 VGPRs).  The tree variant needs them for
+// the packed slab arithmetic of the 4-wide traversal, whose operands live in register pairs: at
+// 5 waves (96 VGPRs) it spills and loses 24 %, at 3 waves it loses 9 % to latency.  The
+// brute-force variants fit 106-124 registers; 5 waves gain 1 % and add scratch traffic.
 // P.xcd_remap (off by default, see vrt_api.hip) renumbers blocks so that the 8 blocks dealt
 // round-robin to the 8 XCDs come from 8 separate bands of the image.
 #define VRT_MEGA_THREADS 64
