@@ -7,12 +7,13 @@
 //   prim_mat int[n_prims]      material index per primitive id (spheres, boxes, triangles)
 //   mat   float4[n_mat]        (r, g, b, type-as-int-bits)
 //   mat_tex, tex_info, tex_data, tri_uv   textured materials, see DevScene
-//   bvh   float4[4*(n_prims-1)] binary LBVH, one 64-byte node per internal node holding the
+//   bvh   float4[4*(n_prims-1)] binary tree (PLOC over Morton order), one 64-byte node per internal node holding the
 //                              boxes of both children:
 //                              (lo0.xyz, hi0.x) (hi0.yz, lo1.xy) (lo1.z, hi1.xyz) (c0, c1, -, -)
 //                              child >= 0: internal node index, child < 0: leaf, primitive = ~child
-//   bvh4  float4[8*(n_prims-1)] the same tree with every second level collapsed: one 128-byte
-//                              node per surviving internal node (index = its binary index)
+//   bvh4  float4[8*(n_prims-1)] the same tree collapsed to four children per node (greedily by
+//                              box area, see k_collapse4_level): one 128-byte node per
+//                              surviving internal node (index = its binary index)
 //                              holding up to four child boxes, struct of arrays:
 //                              lo.x[4] lo.y[4] lo.z[4] hi.x[4] hi.y[4] hi.z[4] code[4] pad[4];
 //                              code as above, VRT_BVH4_EMPTY for an unused slot
