@@ -166,6 +166,7 @@ typedef struct vrt_scene_desc {
 
 #define VRT_MAX_LIGHTS 8
 #define VRT_MAX_DEPTH 15
+#define VRT_NOALLOC_MAX_OFFSETS 65536  /* (x,y) pairs of the sampler table vrt_render_device_noalloc accepts */
 
 /* Primitive ids reported by the library: spheres first, then boxes, then triangles,
  * each in the order given; -1 = miss. */
@@ -275,6 +276,19 @@ int vrt_render_end(vrt_ctx* ctx, vrt_stats* stats_out);
 int vrt_render_device(vrt_ctx* ctx, const vrt_params* params, void* rgba_dev,
                       void* hit_id_dev, void* stream);
 int vrt_fetch_stats(vrt_ctx* ctx, vrt_stats* stats_out);
+
+/* vrt_render_device for callers that cannot allocate device memory: code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc.  No counterpart in the
+ * reference.  Same arguments, same frame, same counts (vrt_fetch_stats), but the call allocates
+ * and frees nothing: the ray counters and the device copy of the sampler table live in a
+ * static device array of the library (one copy per GPU, 16 KiB + 8 bytes x
+ * VRT_NOALLOC_MAX_OFFSETS = 528 KiB, held until the process ends).  Megakernel only
+ * (mode VRT_MODE_WAVEFRONT is refused: its ray queues need a workspace) and
+ * n_sets * spp <= VRT_NOALLOC_MAX_OFFSETS (else VRT_ERR_CAPACITY).  Every call on a GPU,
+ * from whichever context, shares that GPU's array: calls that overlap on one GPU race, and
+ * the counts of a call are gone once the next one starts. */
+int vrt_render_device_noalloc(vrt_ctx* ctx, const vrt_params* params, void* rgba_dev,
+                              void* hit_id_dev, void* stream);
 
 /* RayTracerUnity.ProcessColor (RayTracerUnity.cs:525-562) for n_pixels pixels already in device
  * memory: rgb_dev holds 3 floats per pixel as VRT_OUT_LINEAR_RGB leaves them, rgba_dev receives

@@ -27,6 +27,7 @@ VRT_RAY_CLASSES = 6
 RAY_CLASS_NAMES = ("precheck", "primary", "reflect", "transmit", "shadow", "ao")
 VRT_MAX_LIGHTS = 8
 VRT_MAX_DEPTH = 15
+VRT_NOALLOC_MAX_OFFSETS = 65536
 
 
 class vrt_sphere(C.Structure):
@@ -111,6 +112,6 @@ class vrt_stats(C.Structure):
 EXPORTS = (
     "vrt_create", "vrt_destroy", "vrt_last_error", "vrt_shading_defaults",
     "vrt_params_defaults", "vrt_set_scene", "vrt_set_camera", "vrt_render",
-    "vrt_render_begin", "vrt_render_poll", "vrt_render_end", "vrt_render_device", "vrt_fetch_stats", "vrt_tonemap_device", "vrt_trace_pixel", "vrt_trace_ray", "vrt_sampler_table",
+    "vrt_render_begin", "vrt_render_poll", "vrt_render_end", "vrt_render_device", "vrt_render_device_noalloc", "vrt_fetch_stats", "vrt_tonemap_device", "vrt_trace_pixel", "vrt_trace_ray", "vrt_sampler_table",
     "vrt_pixel_set", "vrt_abi_version",
 )

@@ -49,6 +49,11 @@ struct vrt_ctx {
     float4* d_px_rgba = nullptr; int* d_px_hit = nullptr;
     // wavefront workspace
     WfWorkspace wf; bool wf_two = false; bool wf_short = false;
+    // this device's copy of the library's static scratch array (vrt_render_device_noalloc), the
+    // page-locked staging its sampler table passes through and the event that says the staging is free again
+    unsigned char* static_scratch = nullptr;
+    float* static_stage = nullptr;
+    hipEvent_t ev_static = nullptr; bool static_used = false;
     // last call
     uint64_t last_pixels = 0; int last_mode = 0;
     bool timed = false;
@@ -56,6 +61,15 @@ struct vrt_ctx {
 
 static const unsigned kCtrRing = 64;
 static const size_t kCtrBlock = VRT_CTR_SLOTS * VRT_CTR_STRIDE; // 64-bit words per counter block
+
+// Device memory of vrt_render_device_noalloc: every GPU the library runs on holds one copy of
+// this array from the moment the code object is loaded until the process ends.  Layout: one
+// counter block, then the sampler offset table.  Host code never uses the array's name as an
+// address; vrt_create asks the runtime for the current device's copy (hipGetSymbolAddress) and
+// keeps that pointer in the context.
+static const size_t kStaticCtrBytes = kCtrBlock * sizeof(unsigned long long);
+static const size_t kStaticScratchBytes = kStaticCtrBytes + (size_t)VRT_NOALLOC_MAX_OFFSETS * sizeof(float2);
+static __device__ __align__(256) unsigned char g_vrt_static_scratch[kStaticScratchBytes];
 
 static int fail(vrt_ctx* c, int code, const std::string& msg)
 {
@@ -113,9 +127,19 @@ extern "C" int vrt_create(int device, vrt_ctx** out)
         hipMalloc(&c->d_ctr, VRT_CTR_SLOTS * VRT_CTR_STRIDE * sizeof(unsigned long long)) != hipSuccess ||
         hipMalloc(&c->d_ctr_ring, kCtrRing * kCtrBlock * sizeof(unsigned long long)) != hipSuccess ||
         hipMalloc(&c->d_px_rgba, sizeof(float4)) != hipSuccess ||
-        hipMalloc(&c->d_px_hit, sizeof(int)) != hipSuccess) {
+        hipMalloc(&c->d_px_hit, sizeof(int)) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_static, hipEventDisableTiming) != hipSuccess ||
+        hipHostMalloc((void**)&c->static_stage, (size_t)VRT_NOALLOC_MAX_OFFSETS * sizeof(float2), hipHostMallocDefault) != hipSuccess) {
         delete c;
         return VRT_ERR_HIP;
+    }
+    {   // this device's copy of the static array, asked for with this device current
+        void* scratch = nullptr;
+        if (hipGetSymbolAddress(&scratch, HIP_SYMBOL(g_vrt_static_scratch)) != hipSuccess || !scratch) {
+            delete c;
+            return VRT_ERR_HIP;
+        }
+        c->static_scratch = (unsigned char*)scratch;
     }
     *out = c;
     return VRT_OK;
@@ -153,6 +177,8 @@ extern "C" int vrt_destroy(vrt_ctx* c)
     hipFree(c->d_rec_pixels); hipFree(c->d_segs); hipFree(c->d_seg_counts);
     hipFree(c->d_px_rgba); hipFree(c->d_px_hit);
     hipEventDestroy(c->ev0); hipEventDestroy(c->ev1); hipEventDestroy(c->ev_done);
+    if (c->ev_static) hipEventDestroy(c->ev_static);
+    if (c->static_stage) hipHostFree(c->static_stage);
     hipStreamDestroy(c->stream);
     delete c;
     return VRT_OK;
@@ -452,8 +478,8 @@ static int owned_rows(int H, int index, int count, int rows)
     return n;
 }
 
-// Validates params, uploads the offset table and fills DevParams.
-static int prepare(vrt_ctx* c, const vrt_params* p, DevParams* out)
+// Validates params and fills DevParams (everything but the offset table pointer).
+static int check_params(vrt_ctx* c, const vrt_params* p, DevParams* out)
 {
     if (!c->have_scene || !c->have_cam) return fail(c, VRT_ERR_STATE, "scene or camera not set");
     if (p->spp < 1 || p->spp > 65536) return fail(c, VRT_ERR_INVALID, "spp out of range");
@@ -491,6 +517,15 @@ static int prepare(vrt_ctx* c, const vrt_params* p, DevParams* out)
         if (sh >= 0 && sh <= 6) P.sample_shift = sh;
     }
     P.offsets = nullptr;
+    return VRT_OK;
+}
+
+// check_params + the offset table uploaded to the context's buffer.
+static int prepare(vrt_ctx* c, const vrt_params* p, DevParams* out)
+{
+    int rc = check_params(c, p, out);
+    if (rc) return rc;
+    DevParams& P = *out;
     if (p->offsets) {
         size_t n = (size_t)p->n_sets * p->spp;
         if (n > c->offsets_cap) {
@@ -557,8 +592,10 @@ static int ensure_wf(vrt_ctx* c, size_t slots, bool two, hipStream_t stream)
 }
 
 // Enqueues one frame on `stream`.
+// `ctr_in` = a counter block to count into, already clear (megakernel only), or null for the
+// path's own block.
 static int enqueue_frame(vrt_ctx* c, const vrt_params* p, const DevParams& P, float4* rgba, int* hit,
-                         hipStream_t stream)
+                         hipStream_t stream, unsigned long long* ctr_in = nullptr)
 {
     bool two = (p->flags & VRT_FIX_DIELECTRIC) != 0;
     int mode = p->mode == VRT_MODE_WAVEFRONT ? VRT_MODE_WAVEFRONT : VRT_MODE_MEGAKERNEL;
@@ -582,11 +619,14 @@ static int enqueue_frame(vrt_ctx* c, const vrt_params* p, const DevParams& P, fl
         c->scene.dbg = c->d_ctr; c->last_ctr = c->d_ctr;
         HIPCHK(c, vrt_launch_wavefront(c->scene, c->cam, P, c->use_bvh, two, wf, rgba, hit, c->d_ctr, stream));
     } else {
-        const unsigned slot = c->ring_next % kCtrRing;
-        if (slot == 0)   // frames on one stream run in order, so every block is clean when its turn comes
-            HIPCHK(c, hipMemsetAsync(c->d_ctr_ring, 0, kCtrRing * kCtrBlock * sizeof(unsigned long long), stream));
-        c->ring_next++;
-        unsigned long long* ctr = c->d_ctr_ring + (size_t)slot * kCtrBlock;
+        unsigned long long* ctr = ctr_in;
+        if (!ctr) {
+            const unsigned slot = c->ring_next % kCtrRing;
+            if (slot == 0)   // frames on one stream run in order, so every block is clean when its turn comes
+                HIPCHK(c, hipMemsetAsync(c->d_ctr_ring, 0, kCtrRing * kCtrBlock * sizeof(unsigned long long), stream));
+            c->ring_next++;
+            ctr = c->d_ctr_ring + (size_t)slot * kCtrBlock;
+        }
         c->scene.dbg = ctr; c->last_ctr = ctr;
         HIPCHK(c, vrt_launch_mega(c->scene, c->cam, P, c->use_bvh, two, rgba, hit, ctr, stream));
     }
@@ -757,6 +797,40 @@ extern "C" int vrt_render_device(vrt_ctx* c, const vrt_params* p, void* rgba_dev
     c->timed = false;
     P.flags |= p->flags & VRT_OUT_LINEAR_RGB;
     return enqueue_frame(c, p, P, (float4*)rgba_dev, (int*)hit_id_dev, s);
+}
+
+// vrt_render_device for callers that cannot allocate: the megakernel counts into this device's
+// copy of the library's static scratch array and samples with a copy of the table kept there
+// too.  The array's address on this device was taken in vrt_create; nothing below allocates or frees.
+extern "C" int vrt_render_device_noalloc(vrt_ctx* c, const vrt_params* p, void* rgba_dev, void* hit_id_dev, void* stream)
+{
+    if (!c || !p || !rgba_dev) return fail(c, VRT_ERR_INVALID, "null argument");
+    if (c->pending) return fail(c, VRT_ERR_STATE, "a frame started with vrt_render_begin is still in flight");
+    if (p->mode == VRT_MODE_WAVEFRONT)
+        return fail(c, VRT_ERR_INVALID, "vrt_render_device_noalloc runs the megakernel; the wavefront queues need an allocated workspace");
+    const size_t n_off = p->offsets ? (size_t)(p->n_sets > 0 ? p->n_sets : 0) * (size_t)(p->spp > 0 ? p->spp : 0) : 0;
+    if (n_off > (size_t)VRT_NOALLOC_MAX_OFFSETS)
+        return fail(c, VRT_ERR_CAPACITY, "sampler table larger than VRT_NOALLOC_MAX_OFFSETS entries (n_sets * spp)");
+    HIPCHK(c, hipSetDevice(c->device));
+    DevParams P;
+    int rc = check_params(c, p, &P);
+    if (rc) return rc;
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    unsigned long long* ctr = (unsigned long long*)c->static_scratch;
+    float2* offs = (float2*)(c->static_scratch + kStaticCtrBytes);
+    if (n_off) {
+        // through the context's page-locked staging, once the copy of the previous call has left it
+        if (c->static_used) HIPCHK(c, hipEventSynchronize(c->ev_static));
+        memcpy(c->static_stage, p->offsets, n_off * sizeof(float2));
+        HIPCHK(c, hipMemcpyAsync(offs, c->static_stage, n_off * sizeof(float2), hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipEventRecord(c->ev_static, s));
+        c->static_used = true;
+        P.offsets = offs;
+    }
+    HIPCHK(c, hipMemsetAsync(ctr, 0, kStaticCtrBytes, s));   // the array keeps the last call's counts
+    c->timed = false;
+    P.flags |= p->flags & VRT_OUT_LINEAR_RGB;
+    return enqueue_frame(c, p, P, (float4*)rgba_dev, (int*)hit_id_dev, s, ctr);
 }
 
 extern "C" int vrt_tonemap_device(vrt_ctx* c, const void* rgb_dev, void* rgba_dev, uint64_t n_pixels, void* stream)

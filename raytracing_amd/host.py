@@ -60,6 +60,8 @@ def load_library():
     L.vrt_render_end.argtypes = [vp, C.POINTER(abi.vrt_stats)]
     L.vrt_render_device.restype = C.c_int
     L.vrt_render_device.argtypes = [vp, C.POINTER(abi.vrt_params), vp, vp, vp]
+    L.vrt_render_device_noalloc.restype = C.c_int
+    L.vrt_render_device_noalloc.argtypes = [vp, C.POINTER(abi.vrt_params), vp, vp, vp]
     L.vrt_tonemap_device.restype = C.c_int
     L.vrt_tonemap_device.argtypes = [vp, vp, vp, C.c_uint64, vp]
     L.vrt_fetch_stats.restype = C.c_int
@@ -164,6 +166,12 @@ class Context:
         """Enqueues a frame whose outputs stay in device memory (raw device pointers)."""
         self._chk(self._lib.vrt_render_device(self._h, C.byref(params.c), rgba_ptr, hit_ptr,
                                               stream))
+
+    def render_device_noalloc(self, params, rgba_ptr, hit_ptr=None, stream=None):
+        """render_device for callers that cannot allocate: counters and sampler table in the
+        library's static device array, nothing allocated or freed by the call."""
+        self._chk(self._lib.vrt_render_device_noalloc(self._h, C.byref(params.c), rgba_ptr, hit_ptr,
+                                                      stream))
 
     def tonemap_device(self, rgb_ptr, rgba_ptr, n_pixels, stream=None):
         """3 floats per pixel as VRT_OUT_LINEAR_RGB leaves them -> the frame's 4 floats per pixel."""

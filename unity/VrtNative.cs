@@ -1,4 +1,4 @@
-// P/Invoke binding of libvrt.so (include/vrt.h, ABI version 3) for the Unity host of
+// P/Invoke binding of libvrt.so (include/vrt.h, ABI version 4) for the Unity host of
 // VisualRayTrace.  Goes to Assets/Scripts/RayTracer/Native/; libvrt.so goes to
 // Assets/Plugins/x86_64/.  Every struct is blittable and laid out like its C counterpart:
 // Vector3 = 3 floats, Color = 4 floats, pointers as IntPtr.
@@ -61,6 +61,11 @@ public static class VrtNative
     [DllImport(Lib, CallingConvention = CC)] public static extern int vrt_render_begin(IntPtr ctx, ref Params p, IntPtr rgba, IntPtr hitIds);
     [DllImport(Lib, CallingConvention = CC)] public static extern int vrt_render_poll(IntPtr ctx, out int done);
     [DllImport(Lib, CallingConvention = CC)] public static extern int vrt_render_end(IntPtr ctx, out Stats stats);
+    // frames that stay in GPU memory (stream = a hipStream_t or IntPtr.Zero); _noalloc allocates nothing (megakernel only)
+    [DllImport(Lib, CallingConvention = CC)] public static extern int vrt_render_device(IntPtr ctx, ref Params p, IntPtr rgbaDev, IntPtr hitIdDev, IntPtr stream);
+    [DllImport(Lib, CallingConvention = CC)] public static extern int vrt_render_device_noalloc(IntPtr ctx, ref Params p, IntPtr rgbaDev, IntPtr hitIdDev, IntPtr stream);
+    [DllImport(Lib, CallingConvention = CC)] public static extern int vrt_fetch_stats(IntPtr ctx, out Stats stats);
+    [DllImport(Lib, CallingConvention = CC)] public static extern int vrt_tonemap_device(IntPtr ctx, IntPtr rgbDev, IntPtr rgbaDev, ulong nPixels, IntPtr stream);
     [DllImport(Lib, CallingConvention = CC)] public static extern int vrt_trace_pixel(IntPtr ctx, ref Params p, int h, int v, int sample,
         [Out] PathSeg[] segs, int cap, out int n, out Color rgba, out int hitId);
     [DllImport(Lib, CallingConvention = CC)] public static extern int vrt_trace_ray(IntPtr ctx, ref Params p, ref Vector3 origin, ref Vector3 direction,
