@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define VRT_ABI_VERSION 4
+#define VRT_ABI_VERSION 5
 
 typedef struct vrt_ctx vrt_ctx;
 
@@ -41,7 +41,15 @@ typedef enum vrt_status {
 /* Material classes; values follow RayTraceUtility.MaterialType
  * (Util/RayTraceUtility.cs:106).  The class is what DetermineMaterialType
  * (Util/RayTraceUtility.cs:139-152) derives from the Unity material name. */
-enum { VRT_MAT_SOLID = 1, VRT_MAT_METAL = 2, VRT_MAT_DIELECTRIC = 3 };
+enum {
+    VRT_MAT_SOLID = 1, VRT_MAT_METAL = 2, VRT_MAT_DIELECTRIC = 3,
+    /* The two materials the reference defines but never instantiates (their only users are
+     * commented out): Material/MatteMaterial.cs:44-75 (ambient + Lambert, no shadow test, no
+     * specular lobe) and Material/TransparentMaterial.cs:40-69 (Phong + perfect specular
+     * reflection + BTDF/PerfectTransmitterBTDF.cs:32-69).  A host selects them by class like
+     * the others; the kernels prune them at compile time for scenes without them. */
+    VRT_MAT_MATTE = 4, VRT_MAT_TRANSPARENT = 5
+};
 
 /* Light kinds (Util/RayTraceUtility.cs:495-526). */
 enum { VRT_LIGHT_DIRECTIONAL = 0, VRT_LIGHT_POINT = 1 };
@@ -128,6 +136,18 @@ typedef struct vrt_shading {
     float ao_min_amount[4];
     float ao_ls;
     float ao_color[4];
+    /* MatteMaterial: the two LambertianBRDF coefficients (BRDF/LambertianBRDF.cs:19). */
+    float matte_ka, matte_kd;
+    /* TransparentMaterial(rayDir, ks, exp, ior, kr, kt) (Material/TransparentMaterial.cs:10-25):
+     * the reference never constructs one, so these are host-chosen constructor arguments
+     * (vrt_shading_defaults: Suffern's glass, ks 0.5, exp 2000, ior 1.5, kr 0.1, kt 0.9);
+     * ka/kd are the Phong base's Lambert coefficients.  transp_ray_dir is the rayDir the
+     * constructor hands to PerfectTransmitterBTDF, which keeps it for good and evaluates
+     * Tir() with it (BTDF/PerfectTransmitterBTDF.cs:17-20,57-69); the reference's material
+     * singletons are all built with Vector3.zero (Util/RayTraceUtility.cs:15,27,59). */
+    float transp_ka, transp_kd, transp_ks, transp_exp;
+    float transp_ior, transp_kr, transp_kt;
+    float transp_ray_dir[3];
 } vrt_shading;
 
 /* Material.mainTexture as the tracer reads it (Tracer/WhittedTracer.cs:55-63): a hit on a
@@ -166,6 +186,8 @@ typedef struct vrt_scene_desc {
 
 #define VRT_MAX_LIGHTS 8
 #define VRT_MAX_DEPTH 15
+#define VRT_MAX_GPUS 16                /* GPUs of one vrt_create_multi context */
+#define VRT_MAX_PARTS 64               /* strip sets of vrt_render_begin_parts */
 #define VRT_NOALLOC_MAX_OFFSETS 65536  /* (x,y) pairs of the sampler table vrt_render_device_noalloc accepts */
 
 /* Primitive ids reported by the library: spheres first, then boxes, then triangles,
@@ -238,6 +260,28 @@ int vrt_create(int device, vrt_ctx** out);
 int vrt_destroy(vrt_ctx* ctx);
 const char* vrt_last_error(vrt_ctx* ctx);
 
+/* The same context over n_gpus GPUs of one node (devices = their HIP ordinals, NULL = 0..n_gpus-1).
+ * The Unity host is one process with one main thread (RayTracerUnity.cs:312-352), so the split
+ * lives behind the boundary: vrt_set_scene / vrt_set_camera replicate to every GPU, vrt_render
+ * deals 8-row strips of the frame round-robin to the GPUs (one host thread and stream each, all
+ * samples of a strip on its GPU), gathers the strips to the first GPU with RCCL send/recv over
+ * xGMI, tone-maps there and copies the frame to the caller.  vrt_trace_pixel / vrt_trace_ray run
+ * on the first GPU.  The non-blocking and device-pointer calls are not offered on such a context. */
+int vrt_create_multi(int n_gpus, const int* devices, vrt_ctx** out);
+
+/* Study and test knobs by name ("sample_shift", "packet", "wf_defer", "wf_refill", "wf_max_slots",
+ * "wf_any_cap", "builder", "collapse_parity", "no_big", "xcd_remap"); none changes a result.
+ * builder / collapse_parity / no_big take effect at the next vrt_set_scene.  No counterpart in
+ * the reference. */
+int vrt_set_option(vrt_ctx* ctx, const char* name, long long value);
+
+/* Page-locks a host buffer the caller will hand to vrt_render / vrt_render_begin over and over
+ * (the pinned Color[] PixelColorData, Info/TextureInformation.cs:36,58-63), so that the frame
+ * read-back runs at PCIe speed instead of through the runtime's staging copies.  The buffer must
+ * stay allocated until vrt_host_unregister or vrt_destroy. */
+int vrt_host_register(vrt_ctx* ctx, void* buffer, uint64_t bytes);
+int vrt_host_unregister(vrt_ctx* ctx, void* buffer);
+
 /* Fills the shipped constants (Util/RayTraceUtility.cs:43-47,73-76,484-489,
  * BRDF/LambertianBRDF.cs:19, BRDF/GlossySpecularBRDF.cs:17-20). */
 void vrt_shading_defaults(vrt_shading* out);
@@ -268,6 +312,18 @@ int vrt_render(vrt_ctx* ctx, const vrt_params* params, float* rgba_out,
 int vrt_render_begin(vrt_ctx* ctx, const vrt_params* params, float* rgba_out, int32_t* hit_id_out);
 int vrt_render_poll(vrt_ctx* ctx, int* done);
 int vrt_render_end(vrt_ctx* ctx, vrt_stats* stats_out);
+
+/* The whole frame delivered in n_parts strip sets (1..VRT_MAX_PARTS): part k = the strips s of
+ * params->tile_rows rows with s % n_parts == k, i.e. the rows r with (r / tile_rows) % n_parts == k.
+ * Each part is rendered, only its rows are copied to rgba_out / hit_id_out, and its completion
+ * is visible to vrt_render_poll_parts (parts_done = parts whose rows have landed; they land in
+ * order), so the host uploads the dirty rows of a part as soon as it is done instead of
+ * SetPixels+Apply of the whole texture per pixel (RayTracerUnity.cs:461-477).  params must
+ * describe the whole frame (tile_count <= 1, compact_rows 0).  vrt_render_poll and
+ * vrt_render_end work as after vrt_render_begin; the statistics are those of the whole frame. */
+int vrt_render_begin_parts(vrt_ctx* ctx, const vrt_params* params, float* rgba_out, int32_t* hit_id_out,
+                           int n_parts);
+int vrt_render_poll_parts(vrt_ctx* ctx, int* parts_done);
 
 /* Same, with the outputs left in device memory (rgba_dev, hit_id_dev are device pointers
  * on the context's GPU; hit_id_dev may be NULL).  stream = a hipStream_t or NULL.  The call

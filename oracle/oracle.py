@@ -17,10 +17,9 @@ _lib = None
 
 
 def build(force=False):
-    if force or not os.path.exists(_LIB_PATH) or (
-            os.path.exists(os.path.join(_HERE, "vrt_oracle.c")) and
-            os.path.getmtime(os.path.join(_HERE, "vrt_oracle.c")) > os.path.getmtime(_LIB_PATH)):
-        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    """make decides what is out of date (vrt_oracle.c and include/vrt.h are its prerequisites)."""
+    if os.path.exists(os.path.join(_HERE, "Makefile")) and os.path.exists(os.path.join(_HERE, "vrt_oracle.c")):
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
 
 
 def lib():

@@ -5,7 +5,7 @@ test-side oracle binding can share the data formats.
 """
 import ctypes as C
 
-VRT_ABI_VERSION = 4
+VRT_ABI_VERSION = 5
 
 VRT_OK = 0
 VRT_ERR_INVALID = -1
@@ -14,7 +14,7 @@ VRT_ERR_HIP = -3
 VRT_ERR_STATE = -4
 VRT_ERR_CAPACITY = -5
 
-VRT_MAT_SOLID, VRT_MAT_METAL, VRT_MAT_DIELECTRIC = 1, 2, 3
+VRT_MAT_SOLID, VRT_MAT_METAL, VRT_MAT_DIELECTRIC, VRT_MAT_MATTE, VRT_MAT_TRANSPARENT = 1, 2, 3, 4, 5
 VRT_LIGHT_DIRECTIONAL, VRT_LIGHT_POINT = 0, 1
 (VRT_SAMPLER_REGULAR, VRT_SAMPLER_RANDOM, VRT_SAMPLER_JITTERED, VRT_SAMPLER_NROOKS,
  VRT_SAMPLER_MULTIJITTERED, VRT_SAMPLER_HAMMERSLEY) = range(6)
@@ -27,6 +27,8 @@ VRT_RAY_CLASSES = 6
 RAY_CLASS_NAMES = ("precheck", "primary", "reflect", "transmit", "shadow", "ao")
 VRT_MAX_LIGHTS = 8
 VRT_MAX_DEPTH = 15
+VRT_MAX_GPUS = 16
+VRT_MAX_PARTS = 64
 VRT_NOALLOC_MAX_OFFSETS = 65536
 
 
@@ -59,7 +61,12 @@ class vrt_shading(C.Structure):
                 ("glass_exp", C.c_float),
                 ("glass_eta_in", C.c_float), ("glass_eta_out", C.c_float),
                 ("ao_min_amount", C.c_float * 4), ("ao_ls", C.c_float),
-                ("ao_color", C.c_float * 4)]
+                ("ao_color", C.c_float * 4),
+                ("matte_ka", C.c_float), ("matte_kd", C.c_float),
+                ("transp_ka", C.c_float), ("transp_kd", C.c_float), ("transp_ks", C.c_float),
+                ("transp_exp", C.c_float),
+                ("transp_ior", C.c_float), ("transp_kr", C.c_float), ("transp_kt", C.c_float),
+                ("transp_ray_dir", C.c_float * 3)]
 
 
 class vrt_texture(C.Structure):
@@ -112,6 +119,8 @@ class vrt_stats(C.Structure):
 EXPORTS = (
     "vrt_create", "vrt_destroy", "vrt_last_error", "vrt_shading_defaults",
     "vrt_params_defaults", "vrt_set_scene", "vrt_set_camera", "vrt_render",
-    "vrt_render_begin", "vrt_render_poll", "vrt_render_end", "vrt_render_device", "vrt_render_device_noalloc", "vrt_fetch_stats", "vrt_tonemap_device", "vrt_trace_pixel", "vrt_trace_ray", "vrt_sampler_table",
-    "vrt_pixel_set", "vrt_abi_version",
+    "vrt_render_begin", "vrt_render_poll", "vrt_render_end", "vrt_render_device", "vrt_render_device_noalloc",
+    "vrt_fetch_stats", "vrt_tonemap_device", "vrt_trace_pixel", "vrt_trace_ray", "vrt_sampler_table",
+    "vrt_pixel_set", "vrt_abi_version", "vrt_create_multi", "vrt_set_option", "vrt_host_register",
+    "vrt_host_unregister", "vrt_render_begin_parts", "vrt_render_poll_parts",
 )

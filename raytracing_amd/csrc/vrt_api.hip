@@ -9,55 +9,11 @@
 #include <utility>
 #include <vector>
 
-#include "vrt_launch.h"
+#include "vrt_ctx.h"
 
 // Scenes with at most this many primitives are traced by the brute-force loop whose
 // primitive data stays in scalar registers; larger ones get the LBVH.
 static const uint32_t kBruteMaxPrims = 48;
-
-struct vrt_ctx {
-    int device = 0;
-    std::string err;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_done = nullptr;
-    bool pending = false; // a vrt_render_begin frame is in flight
-    // scene
-    float4 *d_sph = nullptr, *d_box = nullptr, *d_tri = nullptr, *d_mat = nullptr, *d_bvh = nullptr, *d_bvh4 = nullptr, *d_bvh_top = nullptr;
-    int* d_prim_mat = nullptr;
-    DevLight* d_lights = nullptr;
-    float4 *d_aab = nullptr, *d_cam_pre = nullptr, *d_tex_data = nullptr;
-    int* d_mat_tex = nullptr; int4* d_tex_info = nullptr; float2* d_tri_uv = nullptr;
-    std::vector<float4> h_sph, h_box; // host copies for the camera-origin terms
-    DevScene scene;
-    bool have_scene = false, use_bvh = false;
-    float bvh_ms = 0.f;
-    int bvh_depth = 0;
-    // camera
-    DevCam cam;
-    bool have_cam = false;
-    // per-call buffers
-    float2* d_offsets = nullptr; size_t offsets_cap = 0;
-    unsigned long long* d_ctr = nullptr;       // counter block of the multi-kernel paths, cleared per call
-    // The megakernel path takes its counter block from a ring of kCtrRing blocks that is cleared
-    // with one fill every kCtrRing frames instead of one fill launch (~5 us) per frame.
-    unsigned long long* d_ctr_ring = nullptr;
-    unsigned ring_next = 0;
-    unsigned long long* last_ctr = nullptr;    // block the last call counted into
-    float4* d_rgba = nullptr; int* d_hit = nullptr; size_t fb_cap = 0;
-    int* d_rec_pixels = nullptr; vrt_path_seg* d_segs = nullptr; int* d_seg_counts = nullptr;
-    size_t rec_px_cap = 0, rec_seg_cap = 0;
-    float4* d_px_rgba = nullptr; int* d_px_hit = nullptr;
-    // wavefront workspace
-    WfWorkspace wf; bool wf_two = false; bool wf_short = false;
-    // this device's copy of the library's static scratch array (vrt_render_device_noalloc), the
-    // page-locked staging its sampler table passes through and the event that says the staging is free again
-    unsigned char* static_scratch = nullptr;
-    float* static_stage = nullptr;
-    hipEvent_t ev_static = nullptr; bool static_used = false;
-    // last call
-    uint64_t last_pixels = 0; int last_mode = 0;
-    bool timed = false;
-};
 
 static const unsigned kCtrRing = 64;
 static const size_t kCtrBlock = VRT_CTR_SLOTS * VRT_CTR_STRIDE; // 64-bit words per counter block
@@ -71,18 +27,12 @@ static const size_t kStaticCtrBytes = kCtrBlock * sizeof(unsigned long long);
 static const size_t kStaticScratchBytes = kStaticCtrBytes + (size_t)VRT_NOALLOC_MAX_OFFSETS * sizeof(float2);
 static __device__ __align__(256) unsigned char g_vrt_static_scratch[kStaticScratchBytes];
 
-static int fail(vrt_ctx* c, int code, const std::string& msg)
+int vrt_fail(vrt_ctx* c, int code, const std::string& msg)
 {
     if (c) c->err = msg;
     return code;
 }
-
-#define HIPCHK(c, expr)                                                                     \
-    do {                                                                                    \
-        hipError_t e_ = (expr);                                                             \
-        if (e_ != hipSuccess)                                                               \
-            return fail(c, VRT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
-    } while (0)
+static inline int fail(vrt_ctx* c, int code, const std::string& msg) { return vrt_fail(c, code, msg); }
 
 extern "C" int vrt_abi_version(void) { return VRT_ABI_VERSION; }
 
@@ -91,6 +41,7 @@ extern "C" const char* vrt_last_error(vrt_ctx* ctx) { return ctx ? ctx->err.c_st
 extern "C" void vrt_shading_defaults(vrt_shading* s)
 {
     if (!s) return;
+    memset(s, 0, sizeof *s);
     s->solid_ka = 0.5f; s->solid_kd = 0.5f; s->solid_ks = 0.f; s->solid_exp = 1.f;
     s->metal_ka = 0.25f; s->metal_kd = 0.5f; s->metal_ks = 0.15f; s->metal_exp = 100.f; s->metal_kr = 0.75f;
     s->metal_cr[0] = s->metal_cr[1] = s->metal_cr[2] = s->metal_cr[3] = 1.f;
@@ -99,6 +50,13 @@ extern "C" void vrt_shading_defaults(vrt_shading* s)
     s->ao_min_amount[0] = s->ao_min_amount[1] = s->ao_min_amount[2] = 0.05f; s->ao_min_amount[3] = 1.f;
     s->ao_ls = 1.f;
     s->ao_color[0] = s->ao_color[1] = s->ao_color[2] = s->ao_color[3] = 1.f;
+    // Material/MatteMaterial.cs:14-15: two default LambertianBRDFs (BRDF/LambertianBRDF.cs:19)
+    s->matte_ka = 0.5f; s->matte_kd = 0.5f;
+    // Material/TransparentMaterial.cs:10-25: Phong base with default Lambert coefficients; the
+    // other five are constructor arguments the reference never supplies
+    s->transp_ka = 0.5f; s->transp_kd = 0.5f; s->transp_ks = 0.5f; s->transp_exp = 2000.f;
+    s->transp_ior = 1.5f; s->transp_kr = 0.1f; s->transp_kt = 0.9f;
+    s->transp_ray_dir[0] = s->transp_ray_dir[1] = s->transp_ray_dir[2] = 0.f;
 }
 
 extern "C" void vrt_params_defaults(vrt_params* p)
@@ -107,6 +65,85 @@ extern "C" void vrt_params_defaults(vrt_params* p)
     memset(p, 0, sizeof *p);
     p->spp = 1; p->n_sets = 1; p->max_depth = 10; p->range = 30.f;
     p->mode = VRT_MODE_AUTO; p->tile_count = 1; p->tile_rows = 8;
+}
+
+static void options_from_env(VrtOptions& o)
+{
+    auto geti = [](const char* n, long long dflt) { const char* e = getenv(n); return e && *e ? atoll(e) : dflt; };
+    o.xcd_remap = (int)geti("VRT_XCD_REMAP", 0);
+    o.sample_shift = (int)geti("VRT_SAMPLE_SHIFT", -1);
+    o.wf_defer = (int)geti("VRT_WF_DEFER", 1);
+    o.wf_refill = (int)geti("VRT_WF_REFILL", 1);
+    o.wf_max_slots = geti("VRT_WF_MAX_SLOTS", 0);
+    o.wf_any_cap = geti("VRT_WF_ANY_CAP", -1);
+    const char* b = getenv("VRT_BUILDER");
+    o.builder_lbvh = b && strcmp(b, "lbvh") == 0;
+    o.collapse_parity = (int)geti("VRT_COLLAPSE_PARITY", 0);
+    o.no_big = (int)geti("VRT_NO_BIG", 0);
+    o.packet = (int)geti("VRT_PACKET", -1);
+}
+
+extern "C" int vrt_set_option(vrt_ctx* c, const char* name, long long value)
+{
+    if (!c || !name) return fail(c, VRT_ERR_INVALID, "null argument");
+    if (c->pending) return fail(c, VRT_ERR_STATE, "a frame started with vrt_render_begin is still in flight");
+    VrtOptions& o = c->opt;
+    const std::string n(name);
+    if (n == "xcd_remap") o.xcd_remap = value != 0;
+    else if (n == "sample_shift") { if (value < -1 || value > 6) return fail(c, VRT_ERR_INVALID, "sample_shift: -1..6"); o.sample_shift = (int)value; }
+    else if (n == "wf_defer") o.wf_defer = value != 0;
+    else if (n == "wf_refill") o.wf_refill = value != 0;
+    else if (n == "wf_max_slots") o.wf_max_slots = value > 0 ? value : 0;
+    else if (n == "wf_any_cap") o.wf_any_cap = value;
+    else if (n == "builder") o.builder_lbvh = value != 0;
+    else if (n == "collapse_parity") o.collapse_parity = value != 0;
+    else if (n == "no_big") o.no_big = value != 0;
+    else if (n == "fail_after_build") o.fail_after_build = value != 0;
+    else if (n == "packet") { if (value < -1 || value > 1) return fail(c, VRT_ERR_INVALID, "packet: -1, 0 or 1"); o.packet = (int)value; }
+    else return fail(c, VRT_ERR_INVALID, "unknown option " + n);
+    if (c->multi) return vrt_multi_set_option(c, name, value);
+    return VRT_OK;
+}
+
+void SceneBufs::release()
+{
+    hipFree(d_sph); hipFree(d_box); hipFree(d_tri); hipFree(d_mat); hipFree(d_bvh); hipFree(d_bvh4);
+    hipFree(d_prim_mat); hipFree(d_lights); hipFree(d_aab); hipFree(d_cam_pre); hipFree(d_tex_data); hipFree(d_mat_tex);
+    hipFree(d_tex_info); hipFree(d_tri_uv);
+    d_sph = d_box = d_tri = d_mat = d_bvh = d_bvh4 = d_aab = d_cam_pre = d_tex_data = nullptr;
+    d_prim_mat = nullptr; d_lights = nullptr; d_mat_tex = nullptr; d_tex_info = nullptr; d_tri_uv = nullptr;
+    h_sph.clear(); h_box.clear();
+}
+
+static void free_wf(vrt_ctx* c)
+{
+    hipFree(c->wf.arena); hipFree(c->wf.lacc); hipFree(c->wf.counts);
+    hipFree(c->wf.hits); hipFree(c->wf.any.ox); hipFree(c->wf.any_counts);
+    memset(&c->wf, 0, sizeof c->wf);
+}
+
+// Releases everything a context owns; every handle may be null (a half-built context).
+static void teardown(vrt_ctx* c)
+{
+    hipSetDevice(c->device);
+    hipDeviceSynchronize();
+    c->sb.release();
+    free_wf(c);
+    for (OffsetSlot& s : c->off) { hipFree(s.d); s.d = nullptr; }
+    hipFree(c->d_ctr); hipFree(c->d_ctr_ring); hipFree(c->d_rgba); hipFree(c->d_hit);
+    hipFree(c->d_rec_pixels); hipFree(c->d_segs); hipFree(c->d_seg_counts);
+    hipFree(c->d_px_rgba); hipFree(c->d_px_hit);
+    if (c->static_stage) hipHostFree(c->static_stage);
+    for (auto& r : c->registered) hipHostUnregister(r.first);
+    c->registered.clear();
+    if (c->ev0) hipEventDestroy(c->ev0);
+    if (c->ev1) hipEventDestroy(c->ev1);
+    if (c->ev_done) hipEventDestroy(c->ev_done);
+    if (c->ev_static) hipEventDestroy(c->ev_static);
+    for (hipEvent_t e : c->part_ev) hipEventDestroy(e);
+    if (c->stream) hipStreamDestroy(c->stream);
+    (void)hipGetLastError();
+    delete c;
 }
 
 extern "C" int vrt_create(int device, vrt_ctx** out)
@@ -118,70 +155,75 @@ extern "C" int vrt_create(int device, vrt_ctx** out)
     if (device < 0 || device >= n) return VRT_ERR_INVALID;
     vrt_ctx* c = new vrt_ctx();
     c->device = device;
-    memset(&c->scene, 0, sizeof c->scene);
+    memset(&c->sb.scene, 0, sizeof c->sb.scene);
     memset(&c->cam, 0, sizeof c->cam);
     memset(&c->wf, 0, sizeof c->wf);
+    options_from_env(c->opt);
+    void* scratch = nullptr;
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming) != hipSuccess ||
-        hipMalloc(&c->d_ctr, VRT_CTR_SLOTS * VRT_CTR_STRIDE * sizeof(unsigned long long)) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_static, hipEventDisableTiming) != hipSuccess ||
+        hipMalloc(&c->d_ctr, kCtrBlock * sizeof(unsigned long long)) != hipSuccess ||
         hipMalloc(&c->d_ctr_ring, kCtrRing * kCtrBlock * sizeof(unsigned long long)) != hipSuccess ||
         hipMalloc(&c->d_px_rgba, sizeof(float4)) != hipSuccess ||
         hipMalloc(&c->d_px_hit, sizeof(int)) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_static, hipEventDisableTiming) != hipSuccess ||
-        hipHostMalloc((void**)&c->static_stage, (size_t)VRT_NOALLOC_MAX_OFFSETS * sizeof(float2), hipHostMallocDefault) != hipSuccess) {
-        delete c;
+        hipHostMalloc((void**)&c->static_stage, (size_t)VRT_NOALLOC_MAX_OFFSETS * sizeof(float2), hipHostMallocDefault) != hipSuccess ||
+        // this device's copy of the static array, asked for with this device current
+        hipGetSymbolAddress(&scratch, HIP_SYMBOL(g_vrt_static_scratch)) != hipSuccess || !scratch) {
+        teardown(c);   // null handles are skipped
         return VRT_ERR_HIP;
     }
-    {   // this device's copy of the static array, asked for with this device current
-        void* scratch = nullptr;
-        if (hipGetSymbolAddress(&scratch, HIP_SYMBOL(g_vrt_static_scratch)) != hipSuccess || !scratch) {
-            delete c;
-            return VRT_ERR_HIP;
-        }
-        c->static_scratch = (unsigned char*)scratch;
-    }
+    c->static_scratch = (unsigned char*)scratch;
     *out = c;
     return VRT_OK;
 }
 
-static void free_scene(vrt_ctx* c)
+extern "C" int vrt_create_multi(int n_gpus, const int* devices, vrt_ctx** out)
 {
-    hipFree(c->d_sph); hipFree(c->d_box); hipFree(c->d_tri); hipFree(c->d_mat); hipFree(c->d_bvh);
-    hipFree(c->d_bvh4); hipFree(c->d_bvh_top); c->d_bvh_top = nullptr; hipFree(c->d_prim_mat); hipFree(c->d_lights);
-    hipFree(c->d_aab); hipFree(c->d_cam_pre); hipFree(c->d_tex_data); hipFree(c->d_mat_tex);
-    hipFree(c->d_tex_info); hipFree(c->d_tri_uv);
-    c->d_aab = c->d_cam_pre = c->d_tex_data = nullptr;
-    c->d_mat_tex = nullptr; c->d_tex_info = nullptr; c->d_tri_uv = nullptr;
-    c->d_lights = nullptr;
-    c->d_sph = c->d_box = c->d_tri = c->d_mat = c->d_bvh = c->d_bvh4 = nullptr;
-    c->d_prim_mat = nullptr;
-    c->have_scene = false;
-}
-
-static void free_wf(vrt_ctx* c)
-{
-    hipFree(c->wf.arena); hipFree(c->wf.lacc); hipFree(c->wf.counts);
-    hipFree(c->wf.hits); hipFree(c->wf.any.ox); hipFree(c->wf.any_counts);
-    memset(&c->wf, 0, sizeof c->wf);
+    if (!out) return VRT_ERR_INVALID;
+    *out = nullptr;
+    if (n_gpus < 1 || n_gpus > VRT_MAX_GPUS) return VRT_ERR_INVALID;
+    vrt_ctx* c = nullptr;
+    int rc = vrt_create(devices ? devices[0] : 0, &c);
+    if (rc != VRT_OK) return rc;
+    rc = vrt_multi_init(c, n_gpus, devices);
+    if (rc != VRT_OK) { vrt_destroy(c); return rc; }
+    *out = c;
+    return VRT_OK;
 }
 
 extern "C" int vrt_destroy(vrt_ctx* c)
 {
     if (!c) return VRT_ERR_INVALID;
-    hipSetDevice(c->device);
-    hipStreamSynchronize(c->stream);
-    free_scene(c);
-    free_wf(c);
-    hipFree(c->d_offsets); hipFree(c->d_ctr); hipFree(c->d_ctr_ring); hipFree(c->d_rgba); hipFree(c->d_hit);
-    hipFree(c->d_rec_pixels); hipFree(c->d_segs); hipFree(c->d_seg_counts);
-    hipFree(c->d_px_rgba); hipFree(c->d_px_hit);
-    hipEventDestroy(c->ev0); hipEventDestroy(c->ev1); hipEventDestroy(c->ev_done);
-    if (c->ev_static) hipEventDestroy(c->ev_static);
-    if (c->static_stage) hipHostFree(c->static_stage);
-    hipStreamDestroy(c->stream);
-    delete c;
+    if (c->multi) vrt_multi_destroy(c);
+    teardown(c);
     return VRT_OK;
+}
+
+extern "C" int vrt_host_register(vrt_ctx* c, void* p, uint64_t bytes)
+{
+    if (!c || !p || !bytes) return fail(c, VRT_ERR_INVALID, "null argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    for (auto& r : c->registered) if (r.first == p) return fail(c, VRT_ERR_STATE, "buffer is already registered");
+    HIPCHK(c, hipHostRegister(p, (size_t)bytes, hipHostRegisterDefault));
+    c->registered.push_back({p, (size_t)bytes});
+    return VRT_OK;
+}
+
+extern "C" int vrt_host_unregister(vrt_ctx* c, void* p)
+{
+    if (!c || !p) return fail(c, VRT_ERR_INVALID, "null argument");
+    if (c->pending) return fail(c, VRT_ERR_STATE, "a frame started with vrt_render_begin is still in flight");
+    HIPCHK(c, hipSetDevice(c->device));
+    for (size_t i = 0; i < c->registered.size(); ++i)
+        if (c->registered[i].first == p) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            HIPCHK(c, hipHostUnregister(p));
+            c->registered.erase(c->registered.begin() + i);
+            return VRT_OK;
+        }
+    return fail(c, VRT_ERR_INVALID, "buffer was not registered with this context");
 }
 
 template <typename T>
@@ -218,50 +260,40 @@ static int aab_code(const vrt_box& b, float hw[3])
 
 // Terms of the brute-force tests that depend only on the ray origin, for rays leaving the
 // camera: float operations and their order are those of hit_sphere / the box loop.
-static int refresh_cam_pre(vrt_ctx* c)
+static int refresh_cam_pre(vrt_ctx* c, SceneBufs& sb)
 {
-    if (!c->have_scene || !c->have_cam || c->use_bvh) return VRT_OK;
-    const DevScene& S = c->scene;
+    if (!c->have_cam || sb.use_bvh) return VRT_OK;
+    const DevScene& S = sb.scene;
     std::vector<float4> pre((size_t)S.n_sph + S.n_box);
     const float ox = c->cam.ox, oy = c->cam.oy, oz = c->cam.oz;
     for (int i = 0; i < S.n_sph; ++i) {
-        float4 s = c->h_sph[i];
+        float4 s = sb.h_sph[i];
         float x = ox - s.x, y = oy - s.y, z = oz - s.z;
         float cc = (x * x + y * y + z * z) - s.w * s.w;
         pre[i] = make_float4(x, y, z, cc);
     }
     for (int i = 0; i < S.n_box; ++i) {
-        float4 b0 = c->h_box[4 * (size_t)i];
+        float4 b0 = sb.h_box[4 * (size_t)i];
         pre[S.n_sph + i] = make_float4(ox - b0.x, oy - b0.y, oz - b0.z, 0.f);
     }
     if (pre.empty()) return VRT_OK;
-    if (!c->d_cam_pre) HIPCHK(c, hipMalloc(&c->d_cam_pre, pre.size() * sizeof(float4)));
-    HIPCHK(c, hipMemcpy(c->d_cam_pre, pre.data(), pre.size() * sizeof(float4), hipMemcpyHostToDevice));
-    c->scene.cam_pre = c->d_cam_pre;
+    if (!sb.d_cam_pre) HIPCHK(c, hipMalloc(&sb.d_cam_pre, pre.size() * sizeof(float4)));
+    HIPCHK(c, hipMemcpy(sb.d_cam_pre, pre.data(), pre.size() * sizeof(float4), hipMemcpyHostToDevice));
+    sb.scene.cam_pre = sb.d_cam_pre;
     return VRT_OK;
 }
 
-extern "C" int vrt_set_scene(vrt_ctx* c, const vrt_scene_desc* d)
+// Uploads the scene into `sb` (empty on entry) and builds its tree.  On failure the caller
+// releases `sb`; the context's current scene is not touched here.
+static int build_scene(vrt_ctx* c, const vrt_scene_desc* d, SceneBufs& sb)
 {
-    if (!c || !d) return fail(c, VRT_ERR_INVALID, "null argument");
-    if (c->pending) return fail(c, VRT_ERR_STATE, "a frame started with vrt_render_begin is still in flight");
-    if ((d->n_spheres && !d->spheres) || (d->n_boxes && !d->boxes) ||
-        (d->n_triangles && (!d->indices || !d->vertices)) || !d->n_materials || !d->materials ||
-        (d->n_lights && !d->lights))
-        return fail(c, VRT_ERR_INVALID, "scene arrays missing");
-    if (d->n_lights > VRT_MAX_LIGHTS) return fail(c, VRT_ERR_CAPACITY, "more than VRT_MAX_LIGHTS lights");
-    uint64_t n_prims64 = (uint64_t)d->n_spheres + d->n_boxes + d->n_triangles;
-    if (n_prims64 == 0 || n_prims64 > 0x3fffffffu) return fail(c, VRT_ERR_INVALID, "primitive count out of range");
-    uint32_t n_prims = (uint32_t)n_prims64;
-    HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-
+    const uint32_t n_prims = d->n_spheres + d->n_boxes + d->n_triangles;
     std::vector<float4> sph(d->n_spheres), box(4 * (size_t)d->n_boxes), tri(3 * (size_t)d->n_triangles),
         mat(d->n_materials);
     std::vector<int> pm(n_prims);
     for (uint32_t i = 0; i < d->n_materials; ++i) {
         const vrt_material& m = d->materials[i];
-        if (m.type < VRT_MAT_SOLID || m.type > VRT_MAT_DIELECTRIC) return fail(c, VRT_ERR_INVALID, "bad material type");
+        if (m.type < VRT_MAT_SOLID || m.type > VRT_MAT_TRANSPARENT) return fail(c, VRT_ERR_INVALID, "bad material type");
         float4 v; v.x = m.color[0]; v.y = m.color[1]; v.z = m.color[2];
         int t = m.type; memcpy(&v.w, &t, 4);
         mat[i] = v;
@@ -299,8 +331,7 @@ extern "C" int vrt_set_scene(vrt_ctx* c, const vrt_scene_desc* d)
         tri[3 * (size_t)i + 2] = make_float4(cc[0] - a[0], cc[1] - a[1], cc[2] - a[2], 0.f);
         pm[d->n_spheres + d->n_boxes + i] = m;
     }
-
-    for (uint32_t i = 0; i < d->n_lights; ++i)   // everything is validated before the old scene is dropped
+    for (uint32_t i = 0; i < d->n_lights; ++i)
         if (d->lights[i].type != VRT_LIGHT_DIRECTIONAL && d->lights[i].type != VRT_LIGHT_POINT)
             return fail(c, VRT_ERR_INVALID, "bad light type");
 
@@ -341,24 +372,23 @@ extern "C" int vrt_set_scene(vrt_ctx* c, const vrt_scene_desc* d)
         }
     }
 
-    free_scene(c);
-    HIPCHK(c, upload(&c->d_sph, sph));
-    HIPCHK(c, upload(&c->d_box, box));
-    HIPCHK(c, upload(&c->d_tri, tri));
-    HIPCHK(c, upload(&c->d_mat, mat));
-    HIPCHK(c, upload(&c->d_prim_mat, pm));
+    HIPCHK(c, upload(&sb.d_sph, sph));
+    HIPCHK(c, upload(&sb.d_box, box));
+    HIPCHK(c, upload(&sb.d_tri, tri));
+    HIPCHK(c, upload(&sb.d_mat, mat));
+    HIPCHK(c, upload(&sb.d_prim_mat, pm));
 
-    DevScene& S = c->scene;
+    DevScene& S = sb.scene;
     memset(&S, 0, sizeof S);
     S.n_sph = (int)d->n_spheres; S.n_box = (int)d->n_boxes; S.n_tri = (int)d->n_triangles;
     S.n_prims = (int)n_prims;
-    S.sph = c->d_sph; S.box = c->d_box; S.tri = c->d_tri; S.prim_mat = c->d_prim_mat; S.mat = c->d_mat;
+    S.sph = sb.d_sph; S.box = sb.d_box; S.tri = sb.d_tri; S.prim_mat = sb.d_prim_mat; S.mat = sb.d_mat;
     if (!mat_tex.empty()) {
-        HIPCHK(c, upload(&c->d_mat_tex, mat_tex));
-        HIPCHK(c, upload(&c->d_tex_info, tex_info));
-        HIPCHK(c, upload(&c->d_tex_data, tex_data));
-        HIPCHK(c, upload(&c->d_tri_uv, tri_uv));
-        S.mat_tex = c->d_mat_tex; S.tex_info = c->d_tex_info; S.tex_data = c->d_tex_data; S.tri_uv = c->d_tri_uv;
+        HIPCHK(c, upload(&sb.d_mat_tex, mat_tex));
+        HIPCHK(c, upload(&sb.d_tex_info, tex_info));
+        HIPCHK(c, upload(&sb.d_tex_data, tex_data));
+        HIPCHK(c, upload(&sb.d_tri_uv, tri_uv));
+        S.mat_tex = sb.d_mat_tex; S.tex_info = sb.d_tex_info; S.tex_data = sb.d_tex_data; S.tri_uv = sb.d_tri_uv;
     }
     S.n_lights = (int)d->n_lights;
     std::vector<DevLight> lights(d->n_lights ? d->n_lights : 1);
@@ -370,17 +400,20 @@ extern "C" int vrt_set_scene(vrt_ctx* c, const vrt_scene_desc* d)
         o.cr = l.color[0]; o.cg = l.color[1]; o.cb = l.color[2]; o.cast = l.cast_shadows;
         o.lx = l.location[0]; o.ly = l.location[1]; o.lz = l.location[2];
     }
-    HIPCHK(c, upload(&c->d_lights, lights));
-    S.lights = c->d_lights;
+    HIPCHK(c, upload(&sb.d_lights, lights));
+    S.lights = sb.d_lights;
     S.sh = d->shading;
     S.dbg = c->d_ctr;
+    for (uint32_t i = 0; i < d->n_materials; ++i) {
+        if (d->materials[i].type == VRT_MAT_MATTE) S.has_matte = 1;
+        if (d->materials[i].type == VRT_MAT_TRANSPARENT) S.has_transparent = 1;
+    }
 
-    c->use_bvh = n_prims > kBruteMaxPrims;
-    c->bvh_ms = 0.f; c->bvh_depth = 0;
-    if (c->use_bvh) {
+    sb.use_bvh = n_prims > kBruteMaxPrims;
+    sb.bvh_ms = 0.f; sb.bvh_depth = 0;
+    if (sb.use_bvh) {
         // Up to VRT_MAX_BIG primitives whose box is at least half as long as the scene's stay
         // out of the tree (spheres and boxes only; a mesh is expected to be tessellated).
-        // VRT_NO_BIG=1 keeps them in, for study.
         double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
         std::vector<std::pair<double, int>> ext(d->n_spheres + d->n_boxes);
         auto grow = [&](const double l[3], const double h[3]) {
@@ -413,21 +446,19 @@ extern "C" int vrt_set_scene(vrt_ctx* c, const vrt_scene_desc* d)
         std::sort(ext.begin(), ext.end(), [](const std::pair<double, int>& a, const std::pair<double, int>& b) {
             return a.first > b.first || (a.first == b.first && a.second < b.second);
         });
-        const char* nb = getenv("VRT_NO_BIG");
-        if (!(nb && atoi(nb)))
+        if (!c->opt.no_big)
             for (size_t i = 0; i < ext.size() && S.n_big < VRT_MAX_BIG && ext[i].first >= 0.5 * scene_ext; ++i)
                 S.big[S.n_big++] = ext[i].second;
-        HIPCHK(c, hipMalloc(&c->d_bvh, 4 * (size_t)(n_prims - 1) * sizeof(float4)));
-        HIPCHK(c, hipMalloc(&c->d_bvh4, 8 * (size_t)(n_prims - 1) * sizeof(float4)));
-        HIPCHK(c, hipMalloc(&c->d_bvh_top, 8 * VRT_TOP_NODES * sizeof(float4)));
-        S.bvh = c->d_bvh; S.bvh4 = c->d_bvh4; S.bvh_top = c->d_bvh_top;
-        hipError_t e = vrt_build_lbvh(S, c->d_bvh, c->d_bvh4, c->d_bvh_top, &c->bvh_depth, &c->bvh_ms, c->stream);
+        HIPCHK(c, hipMalloc(&sb.d_bvh, 4 * (size_t)(n_prims - 1) * sizeof(float4)));
+        HIPCHK(c, hipMalloc(&sb.d_bvh4, 8 * (size_t)(n_prims - 1) * sizeof(float4)));
+        S.bvh = sb.d_bvh; S.bvh4 = sb.d_bvh4;
+        hipError_t e = vrt_build_lbvh(S, sb.d_bvh, sb.d_bvh4, &sb.bvh_depth, &sb.bvh_ms,
+                                      c->opt.builder_lbvh != 0, c->opt.collapse_parity != 0, c->stream);
         if (e != hipSuccess) return fail(c, VRT_ERR_HIP, std::string("LBVH build: ") + hipGetErrorString(e));
-        if (c->bvh_depth > VRT_BVH_STACK - 2)
-            return fail(c, VRT_ERR_CAPACITY, "LBVH deeper than the traversal stack");
-    }
-    if (!c->use_bvh) {
-        c->h_sph = sph; c->h_box = box;
+        if (sb.bvh_depth > VRT_MAX_TREE_DEPTH)
+            return fail(c, VRT_ERR_CAPACITY, "LBVH deeper than VRT_MAX_TREE_DEPTH levels");
+    } else {
+        sb.h_sph = sph; sb.h_box = box;
         std::vector<float4> aab(2 * (size_t)d->n_boxes);
         bool all = d->n_boxes > 0;
         for (uint32_t i = 0; i < d->n_boxes && all; ++i) {
@@ -440,12 +471,69 @@ extern "C" int vrt_set_scene(vrt_ctx* c, const vrt_scene_desc* d)
             aab[2 * (size_t)i + 1] = make_float4(hw[0], hw[1], hw[2], box[4 * (size_t)i + 3].w);
         }
         if (all) {
-            HIPCHK(c, upload(&c->d_aab, aab));
-            S.aab = c->d_aab; S.all_aab = 1;
+            HIPCHK(c, upload(&sb.d_aab, aab));
+            S.aab = sb.d_aab; S.all_aab = 1;
         }
     }
+    return refresh_cam_pre(c, sb);
+}
+
+// Assembles the scene beside the current one on this context's GPU (vrt_swap_scene_one makes it
+// current).  On failure `nb` is released and the context still renders the scene it had.
+int vrt_build_scene_one(vrt_ctx* c, const vrt_scene_desc* d, SceneBufs& nb)
+{
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = build_scene(c, d, nb);
+    if (rc == VRT_OK && c->opt.fail_after_build) rc = fail(c, VRT_ERR_HIP, "injected failure after the tree build (test option)");
+    if (rc != VRT_OK) nb.release();
+    return rc;
+}
+
+int vrt_swap_scene_one(vrt_ctx* c, SceneBufs& nb)
+{
+    hipError_t se = hipSetDevice(c->device);
+    if (se == hipSuccess) se = hipDeviceSynchronize();   // frames in flight (any stream) still read the old buffers
+    if (se != hipSuccess) { nb.release(); return fail(c, VRT_ERR_HIP, std::string("hipDeviceSynchronize: ") + hipGetErrorString(se)); }
+    c->sb.release();
+    c->sb = std::move(nb);
+    nb = SceneBufs();
     c->have_scene = true;
-    return refresh_cam_pre(c);
+    return VRT_OK;
+}
+
+extern "C" int vrt_set_scene(vrt_ctx* c, const vrt_scene_desc* d)
+{
+    if (!c || !d) return fail(c, VRT_ERR_INVALID, "null argument");
+    if (c->pending) return fail(c, VRT_ERR_STATE, "a frame started with vrt_render_begin is still in flight");
+    if ((d->n_spheres && !d->spheres) || (d->n_boxes && !d->boxes) ||
+        (d->n_triangles && (!d->indices || !d->vertices)) || !d->n_materials || !d->materials ||
+        (d->n_lights && !d->lights))
+        return fail(c, VRT_ERR_INVALID, "scene arrays missing");
+    if (d->n_lights > VRT_MAX_LIGHTS) return fail(c, VRT_ERR_CAPACITY, "more than VRT_MAX_LIGHTS lights");
+    uint64_t n_prims64 = (uint64_t)d->n_spheres + d->n_boxes + d->n_triangles;
+    if (n_prims64 == 0 || n_prims64 > 0x3fffffffu) return fail(c, VRT_ERR_INVALID, "primitive count out of range");
+    if (c->multi) return vrt_multi_set_scene(c, d);
+    // The new scene is assembled beside the old one and swapped in when every upload and the tree
+    // build have succeeded: a failed call leaves the context rendering the scene it had.
+    SceneBufs nb;
+    int rc = vrt_build_scene_one(c, d, nb);
+    if (rc != VRT_OK) return rc;
+    return vrt_swap_scene_one(c, nb);
+}
+
+int vrt_set_camera_one(vrt_ctx* c, const vrt_camera* cam)
+{
+    DevCam& d = c->cam;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipDeviceSynchronize()); // frames in flight still read the old terms
+    d.ox = cam->origin[0]; d.oy = cam->origin[1]; d.oz = cam->origin[2];
+    // PlaneBorderPoints[0] - rayOrigin, rounded once like the C# Vector3 subtraction
+    d.bx = cam->p0[0] - cam->origin[0]; d.by = cam->p0[1] - cam->origin[1]; d.bz = cam->p0[2] - cam->origin[2];
+    d.xx = cam->x_axis[0]; d.xy = cam->x_axis[1]; d.xz = cam->x_axis[2];
+    d.yx = cam->y_axis[0]; d.yy = cam->y_axis[1]; d.yz = cam->y_axis[2];
+    d.width = cam->width; d.height = cam->height;
+    c->have_cam = true;
+    return c->have_scene ? refresh_cam_pre(c, c->sb) : VRT_OK;
 }
 
 extern "C" int vrt_set_camera(vrt_ctx* c, const vrt_camera* cam)
@@ -454,17 +542,8 @@ extern "C" int vrt_set_camera(vrt_ctx* c, const vrt_camera* cam)
     if (c->pending) return fail(c, VRT_ERR_STATE, "a frame started with vrt_render_begin is still in flight");
     if (cam->width <= 0 || cam->height <= 0 || (int64_t)cam->width * cam->height > (1ll << 30))
         return fail(c, VRT_ERR_INVALID, "frame size out of range");
-    DevCam& d = c->cam;
-    d.ox = cam->origin[0]; d.oy = cam->origin[1]; d.oz = cam->origin[2];
-    // PlaneBorderPoints[0] - rayOrigin, rounded once like the C# Vector3 subtraction
-    d.bx = cam->p0[0] - cam->origin[0]; d.by = cam->p0[1] - cam->origin[1]; d.bz = cam->p0[2] - cam->origin[2];
-    d.xx = cam->x_axis[0]; d.xy = cam->x_axis[1]; d.xz = cam->x_axis[2];
-    d.yx = cam->y_axis[0]; d.yy = cam->y_axis[1]; d.yz = cam->y_axis[2];
-    d.width = cam->width; d.height = cam->height;
-    c->have_cam = true;
-    HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipDeviceSynchronize()); // frames in flight still read the old terms
-    return refresh_cam_pre(c);
+    if (c->multi) return vrt_multi_set_camera(c, cam);
+    return vrt_set_camera_one(c, cam);
 }
 
 static int owned_rows(int H, int index, int count, int rows)
@@ -476,6 +555,35 @@ static int owned_rows(int H, int index, int count, int rows)
         n += b - a;
     }
     return n;
+}
+
+// The device copy of the caller's sampler table.  Tables are cached by content in a few slots:
+// an unchanged table costs one comparison and no copy; a new one goes to the slot used longest
+// ago, after everything in flight on the device has finished, so no frame ever samples with
+// another frame's table.
+static int cached_offsets(vrt_ctx* c, const float* table, size_t n, const float2** out)
+{
+    for (OffsetSlot& s : c->off)
+        if (s.d && s.n == n && memcmp(s.host.data(), table, n * sizeof(float2)) == 0) {
+            s.last_use = ++c->off_clock;
+            *out = s.d;
+            return VRT_OK;
+        }
+    OffsetSlot* victim = &c->off[0];
+    for (OffsetSlot& s : c->off) if (s.last_use < victim->last_use) victim = &s;
+    if (victim->d) HIPCHK(c, hipDeviceSynchronize());
+    if (n > victim->cap) {
+        hipFree(victim->d); victim->d = nullptr; victim->cap = 0; victim->n = 0;
+        HIPCHK(c, hipMalloc(&victim->d, n * sizeof(float2)));
+        victim->cap = n;
+    }
+    victim->n = 0;
+    HIPCHK(c, hipMemcpy(victim->d, table, n * sizeof(float2), hipMemcpyHostToDevice));
+    victim->host.assign(table, table + 2 * n);
+    victim->n = n;
+    victim->last_use = ++c->off_clock;
+    *out = victim->d;
+    return VRT_OK;
 }
 
 // Validates params and fills DevParams (everything but the offset table pointer).
@@ -500,11 +608,10 @@ static int check_params(vrt_ctx* c, const vrt_params* p, DevParams* out)
     P.compact = p->compact_rows != 0;
     // Measured on MI355X: giving each XCD one contiguous band of the image costs 1.4-1.7x on
     // every workload (bands differ in work, the slowest XCD sets the frame time), so blocks
-    // keep the hardware's round-robin deal; VRT_XCD_REMAP=1 re-enables the banding for study.
-    P.xcd_remap = 0;
-    if (const char* e = getenv("VRT_XCD_REMAP")) P.xcd_remap = atoi(e);
+    // keep the hardware's round-robin deal unless the xcd_remap option asks for the banding.
+    P.xcd_remap = c->opt.xcd_remap;
     // Megakernel lane split: the largest power of two <= min(spp, 64) sample lanes per pixel that
-    // leaves at most 15 % of the lane-rounds idle; VRT_SAMPLE_SHIFT overrides it for study.
+    // leaves at most 15 % of the lane-rounds idle, unless the sample_shift option fixes it.
     P.sample_shift = 0;
     for (int sh = 6; sh >= 1; --sh) {
         int n = 1 << sh;
@@ -512,33 +619,29 @@ static int check_params(vrt_ctx* c, const vrt_params* p, DevParams* out)
         int rounds = (p->spp + n - 1) / n;
         if ((double)rounds * n <= 1.15 * p->spp) { P.sample_shift = sh; break; }
     }
-    if (const char* e = getenv("VRT_SAMPLE_SHIFT")) {
-        int sh = atoi(e);
-        if (sh >= 0 && sh <= 6) P.sample_shift = sh;
-    }
+    if (c->opt.sample_shift >= 0) P.sample_shift = c->opt.sample_shift;
+    // Wave-uniform traversal of the tree for the camera rays of a wave and the occlusion rays of
+    // their hits: pays when the lanes of a wave belong to few pixels (>= 16 lanes per pixel).
+    P.packet = c->opt.packet >= 0 ? c->opt.packet : (P.sample_shift >= 4 ? 1 : 0);
     P.offsets = nullptr;
     return VRT_OK;
 }
 
-// check_params + the offset table uploaded to the context's buffer.
 static int prepare(vrt_ctx* c, const vrt_params* p, DevParams* out)
 {
     int rc = check_params(c, p, out);
     if (rc) return rc;
-    DevParams& P = *out;
     if (p->offsets) {
-        size_t n = (size_t)p->n_sets * p->spp;
-        if (n > c->offsets_cap) {
-            HIPCHK(c, hipFree(c->d_offsets));
-            c->d_offsets = nullptr; c->offsets_cap = 0;
-            HIPCHK(c, hipMalloc(&c->d_offsets, n * sizeof(float2)));
-            c->offsets_cap = n;
-        }
-        HIPCHK(c, hipMemcpyAsync(c->d_offsets, p->offsets, n * sizeof(float2), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream)); // the caller's table may be reused right away
-        P.offsets = c->d_offsets;
+        rc = cached_offsets(c, p->offsets, (size_t)p->n_sets * p->spp, &out->offsets);
+        if (rc) return rc;
     }
     return VRT_OK;
+}
+
+// Two children per hit: refraction with VRT_FIX_DIELECTRIC, or a transparent material in the scene.
+static bool two_children(const vrt_ctx* c, const vrt_params* p)
+{
+    return (p->flags & VRT_FIX_DIELECTRIC) != 0 || c->sb.scene.has_transparent != 0;
 }
 
 // Sample slots the wavefront workspace holds at most: a band of rows of the frame is in flight
@@ -546,15 +649,27 @@ static int prepare(vrt_ctx* c, const vrt_params* p, DevParams* out)
 // deferred occlusion queries (queues twice that with two children per hit); a frame with fewer samples gets a workspace of its own size.
 static const size_t kWfMaxSlots = 64ull << 20;
 
+// Queue entries beyond the rays a band can hold: every wave of the persistent kernels may leave
+// the last chunk it took partly unwritten, and the kernels run (live + 255) / 256 blocks of four
+// waves, VRT_WF_MAX_BLOCKS at most.
+static size_t wf_slack(size_t live)
+{
+    size_t blocks = (live + 255) / 256;
+    if (blocks > VRT_WF_MAX_BLOCKS) blocks = VRT_WF_MAX_BLOCKS;
+    if (blocks < 1) blocks = 1;
+    return blocks * 4 * VRT_WF_CHUNK;
+}
+
 static int ensure_wf(vrt_ctx* c, size_t slots, bool two, hipStream_t stream)
 {
-    // VRT_WF_DEFER=0 (study, tests): occlusion queries of the bounces traced where they arise
-    const char* e = getenv("VRT_WF_DEFER");
-    const bool defer = !(e && e[0] == '0');
-    if (c->wf.slots >= slots && (c->wf_two || !two) && (c->wf.hits != nullptr) == defer && !c->wf_short && !getenv("VRT_WF_ANY_CAP")) return VRT_OK;
+    const bool defer = c->opt.wf_defer != 0;
+    const bool short_any = c->opt.wf_any_cap >= 0;
+    if (c->wf.slots >= slots && (c->wf_two || !two) && (c->wf.hits != nullptr) == defer && !c->wf_short && !short_any) return VRT_OK;
+    HIPCHK(c, hipDeviceSynchronize());   // a frame in flight may still use the old workspace
     free_wf(c);
     c->wf_short = false;
-    size_t cap = slots * (two ? 2 : 1) + VRT_WF_SLACK;
+    const size_t live = slots * (two ? 2 : 1);
+    size_t cap = live + wf_slack(live);
     HIPCHK(c, hipMalloc(&c->wf.arena, cap * 2 * VRT_QUEUE_ARRAYS * sizeof(float)));
     for (int k = 0; k < 2; ++k) {
         float* b = c->wf.arena + (size_t)k * cap * VRT_QUEUE_ARRAYS;
@@ -580,9 +695,8 @@ static int ensure_wf(vrt_ctx* c, size_t slots, bool two, hipStream_t stream)
         a.skip = (int*)(b + 8 * cap); a.target = (int*)(b + 9 * cap); a.bit = (int*)(b + 10 * cap);
         HIPCHK(c, hipMemsetAsync(a.target, 0xff, cap * sizeof(int), stream));
         c->wf.any_cap = cap;
-        if (const char* v = getenv("VRT_WF_ANY_CAP")) {   // tests: a short queue forces the in-place path
-            long long n = atoll(v);
-            if (n >= 0 && (size_t)n < cap) { c->wf.any_cap = (size_t)n; c->wf_short = true; }
+        if (short_any && (size_t)c->opt.wf_any_cap < cap) {   // tests: a short queue forces the in-place path
+            c->wf.any_cap = (size_t)c->opt.wf_any_cap; c->wf_short = true;
         }
         HIPCHK(c, hipMalloc(&c->wf.any_counts, 3 * (VRT_MAX_DEPTH + 2) * sizeof(int)));
         c->wf.cursors = c->wf.any_counts + (VRT_MAX_DEPTH + 2);
@@ -591,47 +705,69 @@ static int ensure_wf(vrt_ctx* c, size_t slots, bool two, hipStream_t stream)
     return VRT_OK;
 }
 
-// Enqueues one frame on `stream`.
-// `ctr_in` = a counter block to count into, already clear (megakernel only), or null for the
-// path's own block.
+// Enqueues one frame on `stream`.  `ctr` = the counter block to count into (already clear), or
+// null for the path's own block, cleared here.
 static int enqueue_frame(vrt_ctx* c, const vrt_params* p, const DevParams& P, float4* rgba, int* hit,
-                         hipStream_t stream, unsigned long long* ctr_in = nullptr)
+                         hipStream_t stream, unsigned long long* ctr = nullptr)
 {
-    bool two = (p->flags & VRT_FIX_DIELECTRIC) != 0;
+    const bool two = two_children(c, p);
     int mode = p->mode == VRT_MODE_WAVEFRONT ? VRT_MODE_WAVEFRONT : VRT_MODE_MEGAKERNEL;
+    DevScene& S = c->sb.scene;
     if (mode == VRT_MODE_WAVEFRONT) {
         // whole frame if it fits the slot budget, else bands of rows of at least one tile row
         size_t per_row = (size_t)c->cam.width * P.spp;
         size_t want = per_row * (size_t)(P.local_rows > 0 ? P.local_rows : 1);
         size_t min_band = per_row * 8;
-        size_t max_slots = kWfMaxSlots;
-        if (const char* e = getenv("VRT_WF_MAX_SLOTS")) { long long v = atoll(e); if (v > 0) max_slots = (size_t)v; } // tests: force bands
+        size_t max_slots = c->opt.wf_max_slots > 0 ? (size_t)c->opt.wf_max_slots : kWfMaxSlots;
         if (want > max_slots) want = max_slots > min_band ? max_slots : min_band;
         if (want < min_band) want = min_band;
-        if (want * (two ? 2 : 1) + 2 * VRT_WF_SLACK > 0x7fffffffull) return fail(c, VRT_ERR_CAPACITY, "frame row too long for the wavefront queues");
+        const size_t live = want * (two ? 2 : 1);
+        if (live + 2 * wf_slack(live) > 0x7fffffffull) return fail(c, VRT_ERR_CAPACITY, "frame row too long for the wavefront queues");
         int rc = ensure_wf(c, want, two, stream);   // its fills run on the frame's stream, ahead of the kernels
         if (rc) return rc;
         WfWorkspace wf = c->wf;
         wf.slots = want; // a workspace kept from a larger frame still runs this frame in bands of `want`
-        const char* r = getenv("VRT_WF_REFILL");   // 0 (study, tests): queues traced one entry per lane and pass
-        wf.refill = !(r && r[0] == '0');
-        HIPCHK(c, hipMemsetAsync(c->d_ctr, 0, kCtrBlock * sizeof(unsigned long long), stream));
-        c->scene.dbg = c->d_ctr; c->last_ctr = c->d_ctr;
-        HIPCHK(c, vrt_launch_wavefront(c->scene, c->cam, P, c->use_bvh, two, wf, rgba, hit, c->d_ctr, stream));
-    } else {
-        unsigned long long* ctr = ctr_in;
+        wf.refill = c->opt.wf_refill != 0;
         if (!ctr) {
+            HIPCHK(c, hipMemsetAsync(c->d_ctr, 0, kCtrBlock * sizeof(unsigned long long), stream));
+            ctr = c->d_ctr;
+        }
+        S.dbg = ctr; c->last_ctr = ctr;
+        HIPCHK(c, vrt_launch_wavefront(S, c->cam, P, c->sb.use_bvh, two, wf, rgba, hit, ctr, stream));
+    } else {
+        if (!ctr) {
+            // Blocks of the ring are clean when their turn comes only if the frames of a round ran
+            // in order: a frame on another stream than its predecessor's starts a new round once
+            // the device has drained.
+            if (c->ring_stream != stream && c->ring_next % kCtrRing != 0) {
+                HIPCHK(c, hipDeviceSynchronize());
+                c->ring_next = 0;
+            }
+            c->ring_stream = stream;
             const unsigned slot = c->ring_next % kCtrRing;
-            if (slot == 0)   // frames on one stream run in order, so every block is clean when its turn comes
+            if (slot == 0)
                 HIPCHK(c, hipMemsetAsync(c->d_ctr_ring, 0, kCtrRing * kCtrBlock * sizeof(unsigned long long), stream));
             c->ring_next++;
             ctr = c->d_ctr_ring + (size_t)slot * kCtrBlock;
         }
-        c->scene.dbg = ctr; c->last_ctr = ctr;
-        HIPCHK(c, vrt_launch_mega(c->scene, c->cam, P, c->use_bvh, two, rgba, hit, ctr, stream));
+        S.dbg = ctr; c->last_ctr = ctr;
+        HIPCHK(c, vrt_launch_mega(S, c->cam, P, c->sb.use_bvh, two, rgba, hit, ctr, stream));
     }
     c->last_pixels = (uint64_t)P.local_rows * c->cam.width;
     c->last_mode = mode;
+    return VRT_OK;
+}
+
+// A wavefront frame whose ray tree outgrew the queues (two children per hit) has dropped
+// branches: the frame is wrong and the call that produced it must say so.
+static int check_wf_overflow(vrt_ctx* c)
+{
+    if (c->last_mode != VRT_MODE_WAVEFRONT || !c->wf.counts) return VRT_OK;
+    int overflow = 0;
+    HIPCHK(c, hipMemcpy(&overflow, c->wf.counts + VRT_MAX_DEPTH + 2, sizeof(int), hipMemcpyDeviceToHost));
+    if (overflow)
+        return fail(c, VRT_ERR_CAPACITY, "wavefront ray queue overflowed (two children per hit); "
+                                         "use VRT_MODE_MEGAKERNEL for this scene");
     return VRT_OK;
 }
 
@@ -648,17 +784,12 @@ static int read_stats(vrt_ctx* c, vrt_stats* s)
         s->prims_tested += h[i * VRT_CTR_STRIDE + 7];
     }
     s->pixels = c->last_pixels;
-    s->bvh_build_ms = c->bvh_ms;
-    s->bvh_nodes = c->use_bvh ? (uint32_t)(c->scene.n_prims - 1) : 0;
+    s->bvh_build_ms = c->sb.bvh_ms;
+    s->bvh_nodes = c->sb.use_bvh ? (uint32_t)(c->sb.scene.n_prims - 1) : 0;
     s->mode_used = c->last_mode;
     s->gpu_ms = 0.f;
-    if (c->last_mode == VRT_MODE_WAVEFRONT && c->wf.counts) {
-        int overflow = 0;
-        HIPCHK(c, hipMemcpy(&overflow, c->wf.counts + VRT_MAX_DEPTH + 2, sizeof(int), hipMemcpyDeviceToHost));
-        if (overflow)
-            return fail(c, VRT_ERR_CAPACITY, "wavefront ray queue overflowed (two-child refraction); "
-                                             "use VRT_MODE_MEGAKERNEL for this scene");
-    }
+    int rc = check_wf_overflow(c);
+    if (rc) return rc;
     if (c->timed) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) s->gpu_ms = ms;
@@ -689,13 +820,65 @@ static int run_records(vrt_ctx* c, const vrt_params* p, const DevParams& P, cons
         c->rec_seg_cap = nseg;
     }
     HIPCHK(c, hipMemcpyAsync(c->d_rec_pixels, pixels, n * sizeof(int), hipMemcpyHostToDevice, c->stream));
-    bool two = (p->flags & VRT_FIX_DIELECTRIC) != 0;
-    HIPCHK(c, vrt_launch_pixels(c->scene, c->cam, P, c->use_bvh, two, c->d_rec_pixels, n, sample_sel, c->d_segs,
+    const bool two = two_children(c, p);
+    HIPCHK(c, vrt_launch_pixels(c->sb.scene, c->cam, P, c->sb.use_bvh, two, c->d_rec_pixels, n, sample_sel, c->d_segs,
                                 cap, c->d_seg_counts, rgba_dev, hit_dev, ctr, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (counts_out) HIPCHK(c, hipMemcpy(counts_out, c->d_seg_counts, n * sizeof(int), hipMemcpyDeviceToHost));
     if (out && cap > 0)
         HIPCHK(c, hipMemcpy(out, c->d_segs, (size_t)n * cap * sizeof(vrt_path_seg), hipMemcpyDeviceToHost));
+    return VRT_OK;
+}
+
+static int ensure_fb(vrt_ctx* c)
+{
+    size_t npix = (size_t)c->cam.width * c->cam.height;
+    if (npix > c->fb_cap) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        hipFree(c->d_rgba); hipFree(c->d_hit);
+        c->d_rgba = nullptr; c->d_hit = nullptr; c->fb_cap = 0;
+        HIPCHK(c, hipMalloc(&c->d_rgba, npix * sizeof(float4)));
+        HIPCHK(c, hipMalloc(&c->d_hit, npix * sizeof(int)));
+        c->fb_cap = npix;
+    }
+    return VRT_OK;
+}
+
+// Copies the rows a frame call rendered from the context's frame buffer to the caller's: the
+// whole buffer for a whole frame or packed rows, else only the strips this call owns (one strided
+// copy for the full strips, one more for a ragged last strip), so that a frame delivered strip
+// set by strip set moves every row over PCIe once and leaves the other rows as the caller has them.
+static int copy_rows_out(vrt_ctx* c, const DevParams& P, float* rgba_out, int32_t* hit_id_out)
+{
+    const size_t W = (size_t)c->cam.width;
+    const int H = c->cam.height;
+    if (P.tile_count <= 1 || P.compact) {
+        const size_t nout = P.compact ? (size_t)P.local_rows * W : W * H;
+        if (nout == 0) return VRT_OK;
+        HIPCHK(c, hipMemcpyAsync(rgba_out, c->d_rgba, nout * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+        if (hit_id_out)
+            HIPCHK(c, hipMemcpyAsync(hit_id_out, c->d_hit, nout * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        return VRT_OK;
+    }
+    const int R = P.tile_rows, first = P.tile_index * R, period = P.tile_count * R;
+    int n_full = 0, tail_row = -1, tail_rows = 0;
+    for (int a = first; a < H; a += period) {
+        if (a + R <= H) ++n_full; else { tail_row = a; tail_rows = H - a; }
+    }
+    auto strided = [&](void* dst, const void* src, size_t px_bytes) -> hipError_t {
+        if (n_full > 0) {
+            hipError_t e = hipMemcpy2DAsync((char*)dst + (size_t)first * W * px_bytes, (size_t)period * W * px_bytes,
+                                            (const char*)src + (size_t)first * W * px_bytes, (size_t)period * W * px_bytes,
+                                            (size_t)R * W * px_bytes, (size_t)n_full, hipMemcpyDeviceToHost, c->stream);
+            if (e != hipSuccess) return e;
+        }
+        if (tail_rows > 0)
+            return hipMemcpyAsync((char*)dst + (size_t)tail_row * W * px_bytes, (const char*)src + (size_t)tail_row * W * px_bytes,
+                                  (size_t)tail_rows * W * px_bytes, hipMemcpyDeviceToHost, c->stream);
+        return hipSuccess;
+    };
+    HIPCHK(c, strided(rgba_out, c->d_rgba, sizeof(float4)));
+    if (hit_id_out) HIPCHK(c, strided(hit_id_out, c->d_hit, sizeof(int)));
     return VRT_OK;
 }
 
@@ -708,29 +891,14 @@ static int begin_frame(vrt_ctx* c, const vrt_params* p, float* rgba_out, int32_t
     DevParams& P = *P_out;
     int rc = prepare(c, p, &P);
     if (rc) return rc;
-    size_t npix = (size_t)c->cam.width * c->cam.height;
-    if (npix > c->fb_cap) {
-        hipFree(c->d_rgba); hipFree(c->d_hit);
-        c->d_rgba = nullptr; c->d_hit = nullptr; c->fb_cap = 0;
-        HIPCHK(c, hipMalloc(&c->d_rgba, npix * sizeof(float4)));
-        HIPCHK(c, hipMalloc(&c->d_hit, npix * sizeof(int)));
-        c->fb_cap = npix;
-    }
-    size_t nout = P.compact ? (size_t)P.local_rows * c->cam.width : npix;
-    if (P.tile_count > 1 && !P.compact) { // rows of other ranks stay as the caller left them
-        HIPCHK(c, hipMemcpyAsync(c->d_rgba, rgba_out, npix * sizeof(float4), hipMemcpyHostToDevice, c->stream));
-        if (hit_id_out)
-            HIPCHK(c, hipMemcpyAsync(c->d_hit, hit_id_out, npix * sizeof(int), hipMemcpyHostToDevice, c->stream));
-    }
+    rc = ensure_fb(c);
+    if (rc) return rc;
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-    rc = enqueue_frame(c, p, P, c->d_rgba, c->d_hit, c->stream);
+    rc = enqueue_frame(c, p, P, c->d_rgba, hit_id_out ? c->d_hit : nullptr, c->stream);
     if (rc) return rc;
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));
     c->timed = true;
-    HIPCHK(c, hipMemcpyAsync(rgba_out, c->d_rgba, nout * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
-    if (hit_id_out)
-        HIPCHK(c, hipMemcpyAsync(hit_id_out, c->d_hit, nout * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    return VRT_OK;
+    return copy_rows_out(c, P, rgba_out, hit_id_out);
 }
 
 extern "C" int vrt_render(vrt_ctx* c, const vrt_params* p, float* rgba_out, int32_t* hit_id_out, vrt_stats* stats_out)
@@ -738,11 +906,13 @@ extern "C" int vrt_render(vrt_ctx* c, const vrt_params* p, float* rgba_out, int3
     if (!c || !p || !rgba_out) return fail(c, VRT_ERR_INVALID, "null argument");
     if (p->n_record_pixels < 0 || (p->n_record_pixels > 0 && (!p->record_pixels || !p->record_count_out)))
         return fail(c, VRT_ERR_INVALID, "record arguments missing");
+    if (c->multi) return vrt_multi_render(c, p, rgba_out, hit_id_out, stats_out);
     DevParams P;
     int rc = begin_frame(c, p, rgba_out, hit_id_out, &P);
     if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (stats_out) { rc = read_stats(c, stats_out); if (rc) return rc; }
+    if (stats_out) rc = read_stats(c, stats_out); else rc = check_wf_overflow(c);
+    if (rc) return rc;
     if (p->n_record_pixels > 0) {
         rc = run_records(c, p, P, p->record_pixels, p->n_record_pixels, p->record_cap, -1, p->record_out,
                          p->record_count_out, nullptr, nullptr, nullptr);
@@ -754,12 +924,60 @@ extern "C" int vrt_render(vrt_ctx* c, const vrt_params* p, float* rgba_out, int3
 extern "C" int vrt_render_begin(vrt_ctx* c, const vrt_params* p, float* rgba_out, int32_t* hit_id_out)
 {
     if (!c || !p || !rgba_out) return fail(c, VRT_ERR_INVALID, "null argument");
+    if (c->multi) return fail(c, VRT_ERR_INVALID, "a multi-GPU context renders with the blocking vrt_render");
     if (p->n_record_pixels != 0) return fail(c, VRT_ERR_INVALID, "path recording needs the blocking vrt_render");
     DevParams P;
     int rc = begin_frame(c, p, rgba_out, hit_id_out, &P);
     if (rc) return rc;
     HIPCHK(c, hipEventRecord(c->ev_done, c->stream));
     c->pending = true;
+    c->parts_pending = 0;
+    return VRT_OK;
+}
+
+// The frame in n_parts strip sets, each rendered, copied to the caller's buffers (its rows only)
+// and marked with an event of its own.  All parts count into one counter block, so
+// vrt_render_end reports the whole frame.
+extern "C" int vrt_render_begin_parts(vrt_ctx* c, const vrt_params* p, float* rgba_out, int32_t* hit_id_out, int n_parts)
+{
+    if (!c || !p || !rgba_out) return fail(c, VRT_ERR_INVALID, "null argument");
+    if (c->multi) return fail(c, VRT_ERR_INVALID, "a multi-GPU context renders with the blocking vrt_render");
+    if (c->pending) return fail(c, VRT_ERR_STATE, "a frame started with vrt_render_begin is still in flight");
+    if (p->n_record_pixels != 0) return fail(c, VRT_ERR_INVALID, "path recording needs the blocking vrt_render");
+    if (p->flags & VRT_OUT_LINEAR_RGB) return fail(c, VRT_ERR_INVALID, "VRT_OUT_LINEAR_RGB is an output format of vrt_render_device");
+    if (n_parts < 1 || n_parts > VRT_MAX_PARTS) return fail(c, VRT_ERR_INVALID, "n_parts out of range");
+    if (p->tile_count > 1 || p->compact_rows) return fail(c, VRT_ERR_INVALID, "vrt_render_begin_parts cuts the whole frame itself");
+    HIPCHK(c, hipSetDevice(c->device));
+    while ((int)c->part_ev.size() < n_parts) {
+        hipEvent_t e = nullptr;
+        HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c->part_ev.push_back(e);
+    }
+    vrt_params q = *p;
+    q.tile_count = n_parts; q.tile_rows = p->tile_rows > 0 ? p->tile_rows : 8; q.compact_rows = 0;
+    int rc = ensure_fb(c);
+    if (rc) return rc;
+    HIPCHK(c, hipMemsetAsync(c->d_ctr, 0, kCtrBlock * sizeof(unsigned long long), c->stream));
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    uint64_t pixels = 0;
+    for (int k = 0; k < n_parts; ++k) {
+        q.tile_index = k;
+        DevParams P;
+        rc = prepare(c, &q, &P);
+        if (rc) return rc;
+        rc = enqueue_frame(c, &q, P, c->d_rgba, hit_id_out ? c->d_hit : nullptr, c->stream, c->d_ctr);
+        if (rc) return rc;
+        pixels += c->last_pixels;
+        if (k == n_parts - 1) HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+        rc = copy_rows_out(c, P, rgba_out, hit_id_out);
+        if (rc) return rc;
+        HIPCHK(c, hipEventRecord(c->part_ev[k], c->stream));
+    }
+    c->last_pixels = pixels;
+    c->timed = true;
+    HIPCHK(c, hipEventRecord(c->ev_done, c->stream));
+    c->pending = true;
+    c->parts_pending = n_parts;
     return VRT_OK;
 }
 
@@ -774,20 +992,38 @@ extern "C" int vrt_render_poll(vrt_ctx* c, int* done)
     return fail(c, VRT_ERR_HIP, std::string("hipEventQuery: ") + hipGetErrorString(e));
 }
 
+extern "C" int vrt_render_poll_parts(vrt_ctx* c, int* parts_done)
+{
+    if (!c || !parts_done) return fail(c, VRT_ERR_INVALID, "null argument");
+    if (!c->pending || c->parts_pending <= 0) return fail(c, VRT_ERR_STATE, "no frame started with vrt_render_begin_parts in flight");
+    HIPCHK(c, hipSetDevice(c->device));
+    int n = 0;
+    for (; n < c->parts_pending; ++n) {   // parts complete in order: they share one stream
+        hipError_t e = hipEventQuery(c->part_ev[n]);
+        if (e == hipErrorNotReady) { (void)hipGetLastError(); break; }
+        if (e != hipSuccess) return fail(c, VRT_ERR_HIP, std::string("hipEventQuery: ") + hipGetErrorString(e));
+    }
+    *parts_done = n;
+    return VRT_OK;
+}
+
 extern "C" int vrt_render_end(vrt_ctx* c, vrt_stats* stats_out)
 {
     if (!c) return VRT_ERR_INVALID;
     if (!c->pending) return fail(c, VRT_ERR_STATE, "no frame in flight");
     HIPCHK(c, hipSetDevice(c->device));
     c->pending = false;
+    c->parts_pending = 0;
     HIPCHK(c, hipEventSynchronize(c->ev_done));
     if (stats_out) return read_stats(c, stats_out);
-    return VRT_OK;
+    return check_wf_overflow(c);
 }
 
-extern "C" int vrt_render_device(vrt_ctx* c, const vrt_params* p, void* rgba_dev, void* hit_id_dev, void* stream)
+// vrt_render_device enqueues and returns: a wavefront frame whose queues overflowed is reported
+// by the vrt_fetch_stats call that follows the caller's synchronisation, which is therefore the
+// error check of this path.
+int vrt_render_device_one(vrt_ctx* c, const vrt_params* p, void* rgba_dev, void* hit_id_dev, void* stream)
 {
-    if (!c || !p || !rgba_dev) return fail(c, VRT_ERR_INVALID, "null argument");
     if (c->pending) return fail(c, VRT_ERR_STATE, "a frame started with vrt_render_begin is still in flight");
     HIPCHK(c, hipSetDevice(c->device));
     DevParams P;
@@ -799,12 +1035,37 @@ extern "C" int vrt_render_device(vrt_ctx* c, const vrt_params* p, void* rgba_dev
     return enqueue_frame(c, p, P, (float4*)rgba_dev, (int*)hit_id_dev, s);
 }
 
+extern "C" int vrt_render_device(vrt_ctx* c, const vrt_params* p, void* rgba_dev, void* hit_id_dev, void* stream)
+{
+    if (!c || !p || !rgba_dev) return fail(c, VRT_ERR_INVALID, "null argument");
+    if (c->multi) return fail(c, VRT_ERR_INVALID, "a multi-GPU context renders with vrt_render");
+    return vrt_render_device_one(c, p, rgba_dev, hit_id_dev, stream);
+}
+
+// Path records of the listed pixels after a frame, on this context's own GPU.
+int vrt_record_pixels_one(vrt_ctx* c, const vrt_params* p)
+{
+    HIPCHK(c, hipSetDevice(c->device));
+    DevParams P;
+    int rc = prepare(c, p, &P);
+    if (rc) return rc;
+    return run_records(c, p, P, p->record_pixels, p->n_record_pixels, p->record_cap, -1, p->record_out,
+                       p->record_count_out, nullptr, nullptr, nullptr);
+}
+
+int vrt_read_stats_one(vrt_ctx* c, vrt_stats* s)
+{
+    HIPCHK(c, hipSetDevice(c->device));
+    return read_stats(c, s);
+}
+
 // vrt_render_device for callers that cannot allocate: the megakernel counts into this device's
 // copy of the library's static scratch array and samples with a copy of the table kept there
 // too.  The array's address on this device was taken in vrt_create; nothing below allocates or frees.
 extern "C" int vrt_render_device_noalloc(vrt_ctx* c, const vrt_params* p, void* rgba_dev, void* hit_id_dev, void* stream)
 {
     if (!c || !p || !rgba_dev) return fail(c, VRT_ERR_INVALID, "null argument");
+    if (c->multi) return fail(c, VRT_ERR_INVALID, "a multi-GPU context renders with vrt_render");
     if (c->pending) return fail(c, VRT_ERR_STATE, "a frame started with vrt_render_begin is still in flight");
     if (p->mode == VRT_MODE_WAVEFRONT)
         return fail(c, VRT_ERR_INVALID, "vrt_render_device_noalloc runs the megakernel; the wavefront queues need an allocated workspace");
@@ -864,7 +1125,7 @@ extern "C" int vrt_trace_pixel(vrt_ctx* c, const vrt_params* p, int h, int v, in
     if (cap < 0 || (cap > 0 && !segs)) return fail(c, VRT_ERR_INVALID, "bad record buffer");
     int pix = h * c->cam.width + v, n = 0;
     HIPCHK(c, hipMemsetAsync(c->d_ctr, 0, VRT_CTR_SLOTS * VRT_CTR_STRIDE * sizeof(unsigned long long), c->stream));
-    c->scene.dbg = c->d_ctr; c->last_ctr = c->d_ctr;
+    c->sb.scene.dbg = c->d_ctr; c->last_ctr = c->d_ctr;
     rc = run_records(c, p, P, &pix, 1, cap, sample < 0 ? -1 : sample, segs, &n, c->d_px_rgba, c->d_px_hit, c->d_ctr);
     if (rc) return rc;
     float4 col; int id;
@@ -888,9 +1149,9 @@ extern "C" int vrt_trace_ray(vrt_ctx* c, const vrt_params* p, const float origin
     int rc = prepare(c, p, &P);
     if (rc) return rc;
     HIPCHK(c, hipMemsetAsync(c->d_ctr, 0, VRT_CTR_SLOTS * VRT_CTR_STRIDE * sizeof(unsigned long long), c->stream));
-    bool two = (p->flags & VRT_FIX_DIELECTRIC) != 0;
-    c->scene.dbg = c->d_ctr; c->last_ctr = c->d_ctr;
-    HIPCHK(c, vrt_launch_ray(c->scene, P, c->use_bvh, two, origin, direction, depth, c->d_px_rgba, c->d_px_hit,
+    const bool two = two_children(c, p);
+    c->sb.scene.dbg = c->d_ctr; c->last_ctr = c->d_ctr;
+    HIPCHK(c, vrt_launch_ray(c->sb.scene, P, c->sb.use_bvh, two, origin, direction, depth, c->d_px_rgba, c->d_px_hit,
                              c->d_ctr, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     float4 col; int id;

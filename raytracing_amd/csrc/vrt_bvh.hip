@@ -417,34 +417,21 @@ __global__ __launch_bounds__(256) void k_collapse4_level(const float4* __restric
     w[7] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
-// Copies the first VRT_TOP_NODES wide nodes in breadth-first order into a compact table for LDS
-// staging; child codes that point into the table become VRT_TOP_BASE + table index.  One lane.
-__global__ void k_top_table(const float4* __restrict__ wide, float4* __restrict__ top)
+// Writes every binary node's parent index into word 2 of its fourth float4 (-1 at the root): the
+// stackless walk that finishes a query whose traversal stack overflowed climbs with it.
+__global__ __launch_bounds__(256) void k_store_parents(int n_inner, const int* __restrict__ parent, float4* __restrict__ nodes)
 {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    int ids[VRT_TOP_NODES];
-    int n = 1;
-    ids[0] = 0;
-    for (int k = 0; k < n; ++k) {            // breadth-first: entries are appended while scanning
-        const float4* w = wide + 8 * (size_t)ids[k];
-        float4 c = w[6];
-        int code[4] = {__float_as_int(c.x), __float_as_int(c.y), __float_as_int(c.z), __float_as_int(c.w)};
-        for (int j = 0; j < 4; ++j)
-            if (code[j] >= 0 && code[j] != VRT_BVH4_EMPTY && n < VRT_TOP_NODES) { ids[n] = code[j]; code[j] = VRT_TOP_BASE + n; ++n; }
-        for (int q = 0; q < 8; ++q) top[8 * k + q] = w[q];
-        top[8 * k + 6] = make_float4(__int_as_float(code[0]), __int_as_float(code[1]), __int_as_float(code[2]),
-                                     __int_as_float(code[3]));
-    }
-    for (int k = n; k < VRT_TOP_NODES; ++k)
-        for (int q = 0; q < 8; ++q) top[8 * k + q] = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_inner) return;
+    nodes[4 * (size_t)i + 3].z = __int_as_float(parent[i]);
 }
 
 } // namespace
 
 #define BCHK(expr) do { e = (expr); if (e != hipSuccess) goto done; } while (0)
 
-hipError_t vrt_build_lbvh(const DevScene& S, float4* nodes, float4* wide, float4* top, int* depth_out, float* ms_out,
-                          hipStream_t stream)
+hipError_t vrt_build_lbvh(const DevScene& S, float4* nodes, float4* wide, int* depth_out, float* ms_out,
+                          bool radix_tree, bool parity_collapse, hipStream_t stream)
 {
     const int n = S.n_prims;
     hipError_t e = hipSuccess;
@@ -481,8 +468,7 @@ hipError_t vrt_build_lbvh(const DevScene& S, float4* nodes, float4* wide, float4
     hipLaunchKernelGGL(k_morton, dim3(blocks), dim3(256), 0, stream, n, pbox, cb, keys, vals);
     BCHK(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys2, vals, vals2, (size_t)n, 0, 63, stream));
     {
-        const char* bsel = getenv("VRT_BUILDER");
-        bool ploc = !(bsel && strcmp(bsel, "lbvh") == 0);
+        const bool ploc = !radix_tree;
         if (ploc) {
             // cluster arrays, ping-pong; `parked` (4 float4 per node) holds the four box arrays
             int *code_a = nullptr, *code_b = nullptr, *nn = nullptr;
@@ -531,30 +517,25 @@ ploc_done:
     }
     hipLaunchKernelGGL(k_depth, dim3(blocks), dim3(256), 0, stream, n, parent, leaf_parent, depth);
     {
-        // Greedy collapse level by level (the number of levels bounds the traversal stack: three
-        // pushes per level); trees too deep for the stack fall back to the every-second-level
-        // collapse, whose depth is half the binary depth.  `child`/`arrived` are free by now and
-        // serve as the two level queues.
+        // Greedy collapse level by level; `child`/`arrived` are free by now and serve as the two
+        // level queues.  (The every-second-level collapse remains as a study option.)
         int* q0 = (int*)child;
         int* q1 = q0 + (n - 1);
         int* qcount = (int*)arrived;
-        int n_in = 1, levels = 0, root = 0;
-        const char* par = getenv("VRT_COLLAPSE_PARITY");
-        bool greedy = !(par && atoi(par));
+        int n_in = 1, root = 0;
+        bool greedy = !parity_collapse;
         BCHK(hipMemcpyAsync(q0, &root, sizeof(int), hipMemcpyHostToDevice, stream));
         while (greedy && n_in > 0) {
-            if (3 * (levels + 1) + 1 > VRT_BVH4_STACK) { greedy = false; break; }
             BCHK(hipMemsetAsync(qcount, 0, sizeof(int), stream));
             hipLaunchKernelGGL(k_collapse4_level, dim3((n_in + 255) / 256), dim3(256), 0, stream, nodes, wide, q0, n_in, q1,
                                qcount);
             BCHK(hipMemcpyAsync(&n_in, qcount, sizeof(int), hipMemcpyDeviceToHost, stream));
             BCHK(hipStreamSynchronize(stream));
             int* tq = q0; q0 = q1; q1 = tq;
-            ++levels;
         }
         if (!greedy)
             hipLaunchKernelGGL(k_collapse4, dim3((n - 1 + 255) / 256), dim3(256), 0, stream, n - 1, nodes, parent, wide);
-        hipLaunchKernelGGL(k_top_table, dim3(1), dim3(64), 0, stream, wide, top);
+        hipLaunchKernelGGL(k_store_parents, dim3((n - 1 + 255) / 256), dim3(256), 0, stream, n - 1, parent, nodes);
     }
     BCHK(hipEventRecord(e1, stream));
     BCHK(hipGetLastError());

@@ -1,0 +1,126 @@
+// Private state behind the opaque vrt_ctx of include/vrt.h, shared by vrt_api.hip (one GPU) and
+// vrt_multi.hip (several GPUs of one node behind the same entry points).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "vrt_launch.h"
+
+// Study and test knobs.  Environment variables of the same meaning (VRT_XCD_REMAP, VRT_SAMPLE_SHIFT,
+// VRT_WF_DEFER, VRT_WF_REFILL, VRT_WF_MAX_SLOTS, VRT_WF_ANY_CAP, VRT_BUILDER, VRT_COLLAPSE_PARITY,
+// VRT_NO_BIG, VRT_PACKET) are read once, when the context is created; vrt_set_option changes
+// them afterwards.  Nothing on the per-frame path reads the environment.
+struct VrtOptions {
+    int xcd_remap = 0;          // 1: each XCD renders one contiguous band of tiles (measured slower)
+    int sample_shift = -1;      // megakernel lanes per pixel = 1 << shift; -1 = chosen from spp
+    int wf_defer = 1;           // wavefront: occlusion queries of the bounces in a queue of their own
+    int wf_refill = 1;          // wavefront: queues traced with lanes refilled as they finish
+    long long wf_max_slots = 0; // wavefront: sample slots per band (0 = library default)
+    long long wf_any_cap = -1;  // wavefront: capacity of the occlusion-query queue (-1 = full)
+    int builder_lbvh = 0;       // 1: Karras' radix tree instead of PLOC under the 4-wide collapse
+    int collapse_parity = 0;    // 1: collapse every second level instead of by surface area
+    int no_big = 0;             // 1: scene-sized primitives stay in the tree
+    int packet = -1;            // tree scenes: wave-uniform traversal for the rays of one pixel group; -1 = chosen from spp
+    int fail_after_build = 0;   // tests: vrt_set_scene reports a failure after uploads and tree build have succeeded
+};
+
+// Everything vrt_set_scene uploads or builds.  A new scene is assembled in a fresh SceneBufs and
+// swapped in only when every step has succeeded, so a failed call leaves the old scene in place.
+struct SceneBufs {
+    float4 *d_sph = nullptr, *d_box = nullptr, *d_tri = nullptr, *d_mat = nullptr, *d_bvh = nullptr, *d_bvh4 = nullptr;
+    int* d_prim_mat = nullptr;
+    DevLight* d_lights = nullptr;
+    float4 *d_aab = nullptr, *d_cam_pre = nullptr, *d_tex_data = nullptr;
+    int* d_mat_tex = nullptr; int4* d_tex_info = nullptr; float2* d_tri_uv = nullptr;
+    std::vector<float4> h_sph, h_box; // host copies for the camera-origin terms
+    DevScene scene;
+    bool use_bvh = false;
+    float bvh_ms = 0.f;
+    int bvh_depth = 0;
+    void release();
+};
+
+// One cached upload of a sampler offset table.  Frames in flight keep reading the table they were
+// enqueued with, so a changed table goes to another slot instead of overwriting the one in use.
+struct OffsetSlot {
+    float2* d = nullptr;
+    size_t cap = 0, n = 0;
+    std::vector<float> host;   // what the slot holds, for the comparison with the caller's table
+    unsigned long long last_use = 0;
+};
+
+struct VrtMulti;   // vrt_multi.hip
+
+struct vrt_ctx {
+    int device = 0;
+    std::string err;
+    VrtOptions opt;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_done = nullptr;
+    bool pending = false; // a vrt_render_begin frame is in flight
+    // frames delivered in parts (vrt_render_begin_parts)
+    std::vector<hipEvent_t> part_ev;
+    int parts_pending = 0;
+    // scene
+    SceneBufs sb;
+    bool have_scene = false;
+    // camera
+    DevCam cam;
+    bool have_cam = false;
+    // sampler tables
+    OffsetSlot off[4];
+    unsigned long long off_clock = 0;
+    unsigned long long* d_ctr = nullptr;       // counter block of the multi-kernel paths, cleared per call
+    // The megakernel path takes its counter block from a ring of kCtrRing blocks that is cleared
+    // with one fill every kCtrRing frames instead of one fill launch (~5 us) per frame.
+    unsigned long long* d_ctr_ring = nullptr;
+    unsigned ring_next = 0;
+    hipStream_t ring_stream = nullptr;         // stream the frames of the current ring round ran on
+    unsigned long long* last_ctr = nullptr;    // block the last call counted into
+    float4* d_rgba = nullptr; int* d_hit = nullptr; size_t fb_cap = 0;
+    int* d_rec_pixels = nullptr; vrt_path_seg* d_segs = nullptr; int* d_seg_counts = nullptr;
+    size_t rec_px_cap = 0, rec_seg_cap = 0;
+    float4* d_px_rgba = nullptr; int* d_px_hit = nullptr;
+    // host buffers the caller asked us to page-lock (vrt_host_register)
+    std::vector<std::pair<void*, size_t>> registered;
+    // wavefront workspace
+    WfWorkspace wf; bool wf_two = false; bool wf_short = false;
+    // the device's copy of the library's static scratch array (vrt_render_device_noalloc) and the
+    // page-locked staging its sampler table passes through
+    unsigned char* static_scratch = nullptr;
+    float* static_stage = nullptr;
+    hipEvent_t ev_static = nullptr; bool static_used = false;
+    // last call
+    uint64_t last_pixels = 0; int last_mode = 0;
+    bool timed = false;
+    // several GPUs behind this context (vrt_create_multi); null for a one-GPU context
+    VrtMulti* multi = nullptr;
+};
+
+int vrt_fail(vrt_ctx* c, int code, const std::string& msg);
+
+#define HIPCHK(c, expr)                                                                         \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return vrt_fail(c, VRT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+// The single-GPU bodies of the entry points, on this context's own GPU whether or not it is the
+// first GPU of a multi-GPU context.
+int vrt_set_camera_one(vrt_ctx* c, const vrt_camera* cam);
+int vrt_build_scene_one(vrt_ctx* c, const vrt_scene_desc* d, SceneBufs& nb);
+int vrt_swap_scene_one(vrt_ctx* c, SceneBufs& nb);
+int vrt_render_device_one(vrt_ctx* c, const vrt_params* p, void* rgba_dev, void* hit_id_dev, void* stream);
+int vrt_record_pixels_one(vrt_ctx* c, const vrt_params* p);
+int vrt_read_stats_one(vrt_ctx* c, vrt_stats* s);
+
+// vrt_multi.hip: the entry points of include/vrt.h on a context that spans several GPUs.
+int vrt_multi_init(vrt_ctx* c, int n_gpus, const int* devices);
+int vrt_multi_set_scene(vrt_ctx* c, const vrt_scene_desc* d);
+int vrt_multi_set_camera(vrt_ctx* c, const vrt_camera* cam);
+int vrt_multi_render(vrt_ctx* c, const vrt_params* p, float* rgba_out, int32_t* hit_id_out, vrt_stats* stats_out);
+int vrt_multi_set_option(vrt_ctx* c, const char* name, long long value);
+void vrt_multi_destroy(vrt_ctx* c);

@@ -9,8 +9,9 @@
 //   mat_tex, tex_info, tex_data, tri_uv   textured materials, see DevScene
 //   bvh   float4[4*(n_prims-1)] binary tree (PLOC over Morton order), one 64-byte node per internal node holding the
 //                              boxes of both children:
-//                              (lo0.xyz, hi0.x) (hi0.yz, lo1.xy) (lo1.z, hi1.xyz) (c0, c1, -, -)
-//                              child >= 0: internal node index, child < 0: leaf, primitive = ~child
+//                              (lo0.xyz, hi0.x) (hi0.yz, lo1.xy) (lo1.z, hi1.xyz) (c0, c1, parent, -)
+//                              child >= 0: internal node index, child < 0: leaf, primitive = ~child;
+//                              parent = index of the node above, -1 at the root
 //   bvh4  float4[8*(n_prims-1)] the same tree collapsed to four children per node (greedily by
 //                              box area, see k_collapse4_level): one 128-byte node per
 //                              surviving internal node (index = its binary index)
@@ -42,8 +43,6 @@ struct DevScene {
     const float4* mat;
     const float4* bvh;
     const float4* bvh4;
-    const float4* bvh_top; // VRT_TOP_NODES 4-wide nodes from the top of the tree in breadth-first order;
-                           // children inside the table are coded VRT_TOP_BASE + table index
     // brute-force scenes only:
     const float4* aab;     // 2 per box when all_aab: (centre.xyz, face/flip code) (world half extents, r^2)
     int all_aab;           // every box has signed world axes as its axes
@@ -61,6 +60,7 @@ struct DevScene {
     int n_big;
     int big[VRT_MAX_BIG];
     unsigned long long* dbg; // the context's counter block (slots 6, 7: nodes entered, primitives tested)
+    int has_matte, has_transparent; // some material is of class VRT_MAT_MATTE / VRT_MAT_TRANSPARENT
     vrt_shading sh;
 };
 
@@ -85,6 +85,7 @@ struct DevParams {
     int compact;    // outputs indexed by local row instead of global row
     int xcd_remap;  // renumber blocks so that each XCD works on one contiguous band of tiles
     int sample_shift; // megakernel: log2 of the lanes that share one pixel's samples (0..6)
+    int packet;       // tree scenes: rays a wave casts together take the wave-uniform traversal first
 };
 
 // Per-call ray counters: 256 slots x 8 words to spread atomic traffic, summed by the host.
@@ -111,8 +112,7 @@ struct AnyQueue {
 };
 #define VRT_ANYQ_ARRAYS 11
 
-#define VRT_BVH_STACK 64
-#define VRT_BVH4_STACK 96
+// Levels a tree may have.  The traversal stacks live in LDS and are short; a ray that overflows
+// its stack finishes on the stackless walk of the binary tree, so depth costs time, not correctness.
+#define VRT_MAX_TREE_DEPTH 2048
 #define VRT_BVH4_EMPTY ((int)0x80000000)
-#define VRT_TOP_NODES 21
-#define VRT_TOP_BASE 0x40000000

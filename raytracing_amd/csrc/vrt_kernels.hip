@@ -6,49 +6,6 @@
 #include "vrt_trace.h"
 #include "vrt_launch.h"
 
-// ------------------------------------------------------------------ helpers
-
-__device__ __forceinline__ int local_to_global_row(const DevParams& P, int r)
-{
-    if (P.tile_count <= 1) return r;
-    return ((r / P.tile_rows) * P.tile_count + P.tile_index) * P.tile_rows + (r % P.tile_rows);
-}
-
-__device__ __forceinline__ unsigned wave_sum(unsigned v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-
-// Adds this block's counters into one of VRT_CTR_SLOTS slots (one atomic per class per block).
-__device__ __forceinline__ void flush_counters(const Counters& C, unsigned long long* ctr, unsigned block_linear)
-{
-#if VRT_LDS_COUNTERS
-    __syncthreads();   // counts were added to g_lds_ctr as the rays were cast
-    if (threadIdx.x < VRT_RAY_CLASSES && g_lds_ctr[threadIdx.x])
-        atomicAdd(&ctr[(block_linear % VRT_CTR_SLOTS) * VRT_CTR_STRIDE + threadIdx.x],
-                  (unsigned long long)g_lds_ctr[threadIdx.x]);
-    return;
-#endif
-    __shared__ unsigned s_ctr[VRT_RAY_CLASSES];
-    if (threadIdx.x < VRT_RAY_CLASSES) s_ctr[threadIdx.x] = 0;
-    __syncthreads();
-    // one field at a time: an indexed local array of the six counts would live in scratch
-#define VRT_FLUSH(K, FIELD)                                               \
-    {                                                                     \
-        unsigned s = wave_sum(C.FIELD);                                   \
-        if ((threadIdx.x & 63) == 0 && s) atomicAdd(&s_ctr[K], s);        \
-    }
-    VRT_FLUSH(VRT_RAY_PRECHECK, precheck) VRT_FLUSH(VRT_RAY_PRIMARY, primary) VRT_FLUSH(VRT_RAY_REFLECT, reflect)
-    VRT_FLUSH(VRT_RAY_TRANSMIT, transmit) VRT_FLUSH(VRT_RAY_SHADOW, shadow) VRT_FLUSH(VRT_RAY_AO, ao)
-#undef VRT_FLUSH
-    __syncthreads();
-    if (threadIdx.x < VRT_RAY_CLASSES && s_ctr[threadIdx.x])
-        atomicAdd(&ctr[(block_linear % VRT_CTR_SLOTS) * VRT_CTR_STRIDE + threadIdx.x],
-                  (unsigned long long)s_ctr[threadIdx.x]);
-}
-
 // ------------------------------------------------------------------ megakernel
 
 // Block = one wave.  The 64 lanes are split as (64 >> P.sample_shift) pixels x (1 << P.sample_shift)
@@ -98,7 +55,7 @@ __global__ __launch_bounds__(VRT_MEGA_THREADS, BVH ? VRT_BVH_WAVES : (SIMPLE ? V
     const int v = (bx << pw_shift) + (pi & ((1 << pw_shift) - 1));
     const int r = (by << (pshift - pw_shift)) + (pi >> pw_shift);
     const int h = local_to_global_row(P, r);
-    if (BVH) stage_bvh_top(S); else stage_prims(S);
+    if (!BVH) stage_prims(S);
     Counters C = {0, 0, 0, 0, 0, 0};
 #if VRT_LDS_COUNTERS
     if (threadIdx.x < VRT_RAY_CLASSES) g_lds_ctr[threadIdx.x] = 0;
@@ -176,7 +133,7 @@ __global__ __launch_bounds__(64) void k_pixels(DevScene S, DevCam cam, DevParams
                                                int* __restrict__ hit_out, unsigned long long* ctr)
 {
     int i = blockIdx.x * 64 + threadIdx.x;
-    if (BVH) stage_bvh_top(S); else stage_prims(S);
+    if (!BVH) stage_prims(S);
     Counters C = {0, 0, 0, 0, 0, 0};
 #if VRT_LDS_COUNTERS
     if (threadIdx.x < VRT_RAY_CLASSES) g_lds_ctr[threadIdx.x] = 0;
@@ -205,7 +162,7 @@ __global__ __launch_bounds__(64) void k_ray(DevScene S, DevParams P, float ox, f
                                             float dz, int depth, float4* __restrict__ rgba_out,
                                             int* __restrict__ hit_out, unsigned long long* ctr)
 {
-    if (BVH) stage_bvh_top(S); else stage_prims(S);
+    if (!BVH) stage_prims(S);
     Counters C = {0, 0, 0, 0, 0, 0};
 #if VRT_LDS_COUNTERS
     if (threadIdx.x < VRT_RAY_CLASSES) g_lds_ctr[threadIdx.x] = 0;

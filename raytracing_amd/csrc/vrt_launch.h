@@ -47,10 +47,13 @@ hipError_t vrt_launch_wavefront(const DevScene& S, const DevCam& cam, const DevP
                                 unsigned long long* ctr, hipStream_t stream);
 
 // LBVH build on the device.  prim arrays are those of DevScene; writes 4*(n_prims-1) float4
-// binary nodes to `nodes` and 8*(n_prims-1) float4 of 4-wide nodes to `wide` (slots of absorbed
-// nodes stay unwritten) and the 8*VRT_TOP_NODES float4 breadth-first top table to `top`.  Returns the binary tree depth in *depth_out.  Synchronises the stream.
-hipError_t vrt_build_lbvh(const DevScene& S, float4* nodes, float4* wide, float4* top, int* depth_out, float* ms_out,
-                          hipStream_t stream);
+// binary nodes (with parent indices) to `nodes` and 8*(n_prims-1) float4 of 4-wide nodes to `wide`
+// (slots of absorbed nodes stay unwritten).  Returns the binary tree depth in *depth_out.
+// Synchronises the stream.
+// radix_tree: Karras' radix tree instead of PLOC clustering; parity_collapse: every second level
+// becomes a wide node instead of the surface-area-guided collapse.
+hipError_t vrt_build_lbvh(const DevScene& S, float4* nodes, float4* wide, int* depth_out, float* ms_out,
+                          bool radix_tree, bool parity_collapse, hipStream_t stream);
 
 // process_color over n pixels: 3 floats in, 4 floats out.
 hipError_t vrt_launch_tonemap(const float* rgb, float4* rgba, size_t n, hipStream_t stream);

@@ -303,100 +303,17 @@ __device__ __forceinline__ bool slab_test(f3 lo, f3 hi, f3 o, f3 inv, float tmax
     return t0 <= t1 * 1.0000004f;
 }
 
-// Lanes per block of the translation unit that includes this header; sizes the LDS stack.
+// Lanes per block of the translation unit that includes this header, and traversal-stack entries
+// per lane: together they size the one traversal stack of a block in LDS, [entry][lane], 8-byte
+// entries (conflict-free).  16 entries x 64 lanes = 8 KiB per one-wave block, so 16 such blocks
+// fit a CU beside their counters.
 #ifndef VRT_STACK_LANES
 #define VRT_STACK_LANES 64
 #endif
-#define VRT_LDS_STACK 16
-
-// Stack-based traversal of the 2-wide LBVH, nearer child first.  The result does not depend
-// on the traversal order because candidates are ranked by (t, id).
-// Leaves go through the same loop head as inner nodes, so there is one primitive-test site and
-// lanes that sit on leaves run it together.  The first VRT_LDS_STACK stack entries of a lane
-// live in LDS ([entry][lane], conflict-free); deeper entries spill to private memory, which
-// real scenes rarely reach because only the far child of a two-hit node is ever pushed.
-__device__ __forceinline__ Hit intersect_bvh(const DevScene& S, f3 o, f3 d, float maxd, float tlim, int skip, bool ANY)
-{
-    __shared__ int lds_stack[VRT_LDS_STACK * VRT_STACK_LANES];
-    int* my_lds = lds_stack + threadIdx.x;
-    Hit best; best.t = INFINITY; best.prim = -1; best.aux = 0;
-    if (is_zero3(d)) return best;
-    f3 inv = mk3(1.f / d.x, 1.f / d.y, 1.f / d.z);
-    for (int k = 0; k < S.n_big; ++k) {   // scene-sized primitives kept out of the tree
-        const int id = S.big[k];
-        if (id != skip) test_prim(S, id, o, d, maxd, best);
-        if (ANY && best.prim >= 0) { if (best.t < tlim) return best; best.prim = -1; best.t = INFINITY; }
-    }
-    int deep[VRT_BVH_STACK - VRT_LDS_STACK];
-    int sp = 0;
-    int node = 0;
-    // every node is entered at most once; the bound only guards against a corrupt tree
-    for (int guard = 2 * S.n_prims + 8; guard > 0; --guard) {
-        bool pop = true;
-        if (node >= 0) {
-            const float4* n = S.bvh + 4 * (size_t)node;
-            float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
-            int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
-            float lim = best.prim >= 0 ? best.t : fminf(maxd, tlim);
-            float tn0, tn1;
-            bool h0 = slab_test(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), o, inv, lim, tn0);
-            bool h1 = slab_test(mk3(n1.z, n1.w, n2.x), mk3(n2.y, n2.z, n2.w), o, inv, lim, tn1);
-            if (h0 && h1) {
-                bool swap = tn1 < tn0;
-                int farc = swap ? c0 : c1;
-                node = swap ? c1 : c0;
-                if (sp < VRT_LDS_STACK) my_lds[sp * VRT_STACK_LANES] = farc;
-                else if (sp < VRT_BVH_STACK) deep[sp - VRT_LDS_STACK] = farc;
-                sp++;
-                pop = false;
-            } else if (h0 || h1) {
-                node = h0 ? c0 : c1;
-                pop = false;
-            }
-        } else {
-            int id = ~node;
-            if (id != skip) test_prim(S, id, o, d, maxd, best);
-            if (ANY && best.prim >= 0) { if (best.t < tlim) return best; best.prim = -1; best.t = INFINITY; }
-        }
-        if (pop) {
-            if (sp == 0) break;
-            --sp;
-            node = sp < VRT_LDS_STACK ? my_lds[sp * VRT_STACK_LANES] : deep[sp - VRT_LDS_STACK];
-        }
-    }
-    return best;
-}
-
-// VRT_BVH4=1 (default) traverses the 4-wide collapse of the LBVH, VRT_BVH4=0 the binary tree.
-#ifndef VRT_BVH4
-#define VRT_BVH4 1
+#ifndef VRT_TRAV_STACK
+#define VRT_TRAV_STACK 16
 #endif
-#ifndef VRT_LDS_STACK4
-#define VRT_LDS_STACK4 12
-#endif
-#ifndef VRT_LEAF_BATCH
-#define VRT_LEAF_BATCH 0
-#endif
-
-// VRT_LDS_TOP=1 stages the top VRT_TOP_NODES nodes of the 4-wide tree in LDS (whole block calls
-// stage_bvh_top once) and the traversal reads nodes coded >= VRT_TOP_BASE from there.
-#ifndef VRT_LDS_TOP
-#define VRT_LDS_TOP 0
-#endif
-#ifndef VRT_SIGN_SLAB
-#define VRT_SIGN_SLAB 0
-#endif
-#if VRT_LDS_TOP
-__shared__ float4 g_lds_top[8 * VRT_TOP_NODES];
-__device__ __forceinline__ void stage_bvh_top(const DevScene& S)
-{
-    if (S.bvh_top)
-        for (int k = threadIdx.x; k < 8 * VRT_TOP_NODES; k += blockDim.x) g_lds_top[k] = S.bvh_top[k];
-    __syncthreads();
-}
-#else
-__device__ __forceinline__ void stage_bvh_top(const DevScene&) {}
-#endif
+__shared__ unsigned long long g_lds_stack[VRT_TRAV_STACK * VRT_STACK_LANES];
 
 // Orders two (tnear, code) candidates, nearer first.
 __device__ __forceinline__ void order2(float& ta, int& ca, float& tb, int& cb)
@@ -406,7 +323,8 @@ __device__ __forceinline__ void order2(float& ta, int& ca, float& tb, int& cb)
     int c = s ? cb : ca; cb = s ? ca : cb; ca = c;
 }
 
-// Debug build only (-DVRT_COUNT_NODES=1): adds the number of active lanes to counter word `k`.
+// Debug build only (-DVRT_COUNT_NODES=1): adds the number of active lanes to counter word `k`
+// (6: inner nodes entered, 7: primitives tested).
 #ifndef VRT_COUNT_NODES
 #define VRT_COUNT_NODES 0
 #endif
@@ -419,160 +337,288 @@ __device__ __forceinline__ void count_lanes(const DevScene& S, int k)
 #endif
 }
 
-// Stack-based traversal of the 4-wide tree.  One step loads one 128-byte node and tests its
-// four child boxes; the hit children are visited nearest first, the others wait on the stack
-// as (tnear, code) pairs and are dropped at pop time when a closer hit has been found since.
-// The first VRT_LDS_STACK4 entries of a lane live in LDS ([entry][lane], 8-byte entries,
-// conflict-free), deeper ones in private memory.  As in the binary traversal the result does
-// not depend on the visiting order because candidates are ranked by (t, id).
-__device__ __forceinline__ Hit intersect_bvh4(const DevScene& S, f3 o, f3 d, float maxd, float tlim, int skip, bool ANY)
+// One ray on its way through the tree.
+struct Trav {
+    f3 o, d, inv;
+    float maxd, tlim, lim0; // range of the query, "nearer than" bound of an any-hit query, min of both
+    int skip;               // primitive the ray was spawned on
+    Hit best;
+    int node;               // what to look at next: >= 0 inner node, < 0 leaf ~primitive
+    int sp;                 // entries on the lane's stack
+    bool ovf;               // an entry did not fit the stack and was dropped
+};
+
+__device__ __forceinline__ void trav_begin(Trav& T, f3 o, f3 d, float maxd, float tlim, int skip)
 {
-    __shared__ unsigned long long lds_stack4[VRT_LDS_STACK4 * VRT_STACK_LANES];
-    unsigned long long* my_lds = lds_stack4 + threadIdx.x;
-    Hit best; best.t = INFINITY; best.prim = -1; best.aux = 0;
-    if (is_zero3(d)) return best;
-    const f3 inv = mk3(1.f / d.x, 1.f / d.y, 1.f / d.z);
-    const float lim0 = fminf(maxd, tlim);
-#if VRT_SIGN_SLAB
-    // Rows of a node that hold this ray's entry and exit plane per axis (rows 0..2 = lo.xyz,
-    // 3..5 = hi.xyz): with a negative direction component the ray enters through hi.  For
-    // finite products (plane - o) * inv is monotonic in the plane, so these are exactly the
-    // min and max of the two products the unordered test forms; a NaN product (0 * inf) is
-    // dropped by the min/max over the axes on one side only, which keeps more candidates, never fewer.
-    const int rnx = inv.x < 0.f ? 3 : 0, rny = inv.y < 0.f ? 4 : 1, rnz = inv.z < 0.f ? 5 : 2;
-#endif
-    for (int k = 0; k < S.n_big; ++k) {   // scene-sized primitives kept out of the tree
+    T.o = o; T.d = d; T.inv = mk3(1.f / d.x, 1.f / d.y, 1.f / d.z);
+    T.maxd = maxd; T.tlim = tlim; T.lim0 = fminf(maxd, tlim); T.skip = skip;
+    T.best.t = INFINITY; T.best.prim = -1; T.best.aux = 0;
+    T.node = 0; T.sp = 0; T.ovf = false;
+}
+
+// Distance beyond which nothing can matter to the query any more.
+__device__ __forceinline__ float trav_limit(const Trav& T) { return T.best.prim >= 0 ? T.best.t : T.lim0; }
+
+// The four slab tests of slab_test() on one 128-byte node, children (0,1) and (2,3) as packed
+// pairs (v_pk_add_f32 / v_pk_mul_f32).  Unused child slots hold boxes at +inf, which no ray passes.
+struct Slab4 { float t0, t1, t2, t3; bool h0, h1, h2, h3; };
+__device__ __forceinline__ Slab4 slab4(float4 lx, float4 ly, float4 lz, float4 hx, float4 hy, float4 hz, f3 o, f3 inv,
+                                       float lim)
+{
+    Slab4 r;
+    const v2f ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
+    const v2f ix = {inv.x, inv.x}, iy = {inv.y, inv.y}, iz = {inv.z, inv.z};
+    const v2f ax01 = (v2f{lx.x, lx.y} - ox) * ix, ax23 = (v2f{lx.z, lx.w} - ox) * ix;
+    const v2f bx01 = (v2f{hx.x, hx.y} - ox) * ix, bx23 = (v2f{hx.z, hx.w} - ox) * ix;
+    const v2f ay01 = (v2f{ly.x, ly.y} - oy) * iy, ay23 = (v2f{ly.z, ly.w} - oy) * iy;
+    const v2f by01 = (v2f{hy.x, hy.y} - oy) * iy, by23 = (v2f{hy.z, hy.w} - oy) * iy;
+    const v2f az01 = (v2f{lz.x, lz.y} - oz) * iz, az23 = (v2f{lz.z, lz.w} - oz) * iz;
+    const v2f bz01 = (v2f{hz.x, hz.y} - oz) * iz, bz23 = (v2f{hz.z, hz.w} - oz) * iz;
+#define VRT_SLAB4(T, H, AX, BX, AY, BY, AZ, BZ)                                                       \
+    {                                                                                                 \
+        float n_ = fmaxf(fmaxf(fminf(AX, BX), fminf(AY, BY)), fmaxf(fminf(AZ, BZ), 0.f));             \
+        float f_ = fminf(fminf(fmaxf(AX, BX), fmaxf(AY, BY)), fminf(fmaxf(AZ, BZ), lim));             \
+        T = n_; H = n_ <= f_ * 1.0000004f;                                                            \
+    }
+    VRT_SLAB4(r.t0, r.h0, ax01.x, bx01.x, ay01.x, by01.x, az01.x, bz01.x)
+    VRT_SLAB4(r.t1, r.h1, ax01.y, bx01.y, ay01.y, by01.y, az01.y, bz01.y)
+    VRT_SLAB4(r.t2, r.h2, ax23.x, bx23.x, ay23.x, by23.x, az23.x, bz23.x)
+    VRT_SLAB4(r.t3, r.h3, ax23.y, bx23.y, ay23.y, by23.y, az23.y, bz23.y)
+#undef VRT_SLAB4
+    return r;
+}
+
+__device__ __forceinline__ void trav_push(Trav& T, unsigned long long* my_lds, float tnear, int code)
+{
+    if (T.sp < VRT_TRAV_STACK) {
+        my_lds[T.sp * VRT_STACK_LANES] = ((unsigned long long)__float_as_uint(tnear) << 32) | (unsigned)code;
+        T.sp++;
+    } else {
+        T.ovf = true;   // dropped: the query is finished by trav_stackless()
+    }
+}
+
+// Inner-node step of the per-lane traversal of the 4-wide tree: loads the node T.node, tests its
+// four child boxes, enters the nearest hit child and leaves the others on the stack as
+// (tnear, code) pairs (an any-hit query enters the first hit child and keeps the others with
+// distance 0).  Returns true when no child was hit, i.e. the caller has to pop.
+__device__ __forceinline__ bool trav_inner(const DevScene& S, Trav& T, unsigned long long* my_lds, bool any)
+{
+    count_lanes(S, 6);
+    const float4* n = S.bvh4 + 8 * (size_t)T.node;
+    const float4 lx = n[0], ly = n[1], lz = n[2], hx = n[3], hy = n[4], hz = n[5], cc = n[6];
+    int c0 = __float_as_int(cc.x), c1 = __float_as_int(cc.y), c2 = __float_as_int(cc.z), c3 = __float_as_int(cc.w);
+    Slab4 r = slab4(lx, ly, lz, hx, hy, hz, T.o, T.inv, trav_limit(T));
+    if (any) {
+        bool taken = false;
+#define VRT_VISIT_ANY(H, C) if (H) { if (!taken) { T.node = C; taken = true; } else trav_push(T, my_lds, 0.f, C); }
+        VRT_VISIT_ANY(r.h0, c0) VRT_VISIT_ANY(r.h1, c1) VRT_VISIT_ANY(r.h2, c2) VRT_VISIT_ANY(r.h3, c3)
+#undef VRT_VISIT_ANY
+        return !taken;
+    }
+    float t0 = r.h0 ? r.t0 : INFINITY, t1 = r.h1 ? r.t1 : INFINITY, t2 = r.h2 ? r.t2 : INFINITY, t3 = r.h3 ? r.t3 : INFINITY;
+    order2(t0, c0, t1, c1); order2(t2, c2, t3, c3);
+    order2(t0, c0, t2, c2); order2(t1, c1, t3, c3);
+    order2(t1, c1, t2, c2);
+    if (!(t0 < INFINITY)) return true;
+    T.node = c0;
+    if (t3 < INFINITY) trav_push(T, my_lds, t3, c3);
+    if (t2 < INFINITY) trav_push(T, my_lds, t2, c2);
+    if (t1 < INFINITY) trav_push(T, my_lds, t1, c1);
+    return false;
+}
+
+// Leaf step: tests primitive ~T.node.  Returns true when an any-hit query has its answer.
+__device__ __forceinline__ bool trav_leaf(const DevScene& S, Trav& T, bool any)
+{
+    const int id = ~T.node;
+    count_lanes(S, 7);
+    if (id != T.skip) test_prim(S, id, T.o, T.d, T.maxd, T.best);
+    if (any && T.best.prim >= 0) {
+        if (T.best.t < T.tlim) return true;
+        T.best.prim = -1; T.best.t = INFINITY;
+    }
+    return false;
+}
+
+// Takes the next entry that can still matter off the stack.  Returns false when the stack is empty.
+__device__ __forceinline__ bool trav_pop(Trav& T, const unsigned long long* my_lds)
+{
+    const float lim = trav_limit(T);
+    while (T.sp > 0) {
+        --T.sp;
+        const unsigned long long e = my_lds[T.sp * VRT_STACK_LANES];
+        if (!(__uint_as_float((unsigned)(e >> 32)) > lim)) { T.node = (int)(unsigned)e; return true; }
+    }
+    return false;
+}
+
+// Primitives kept out of the tree (DevScene.big), tested ahead of the traversal.  Returns true
+// when an any-hit query has its answer.
+__device__ __forceinline__ bool trav_big(const DevScene& S, Trav& T, bool any)
+{
+    for (int k = 0; k < S.n_big; ++k) {
         const int id = S.big[k];
         count_lanes(S, 7);
-        if (id != skip) test_prim(S, id, o, d, maxd, best);
-        if (ANY && best.prim >= 0) { if (best.t < tlim) return best; best.prim = -1; best.t = INFINITY; }
+        if (id != T.skip) test_prim(S, id, T.o, T.d, T.maxd, T.best);
+        if (any && T.best.prim >= 0) {
+            if (T.best.t < T.tlim) return true;
+            T.best.prim = -1; T.best.t = INFINITY;
+        }
     }
-    unsigned long long deep[VRT_BVH4_STACK - VRT_LDS_STACK4];
-    int sp = 0;
-    int node = VRT_LDS_TOP ? VRT_TOP_BASE : 0;
-    bool done = false;
+    return false;
+}
+
+// Finishes a query whose stack overflowed: a walk of the whole binary tree that needs no stack,
+// only the parent index every binary node carries (word 2 of its fourth float4).  State = the
+// inner node `cur` and which of its two children comes next (k = 2: both done, go up); a
+// subtree is entered when the ray passes its box nearer than the best hit so far.  Every
+// primitive the ray can reach is tested (again), so with candidates ranked by (t, id) the result
+// is that of a traversal with an unbounded stack.  Slow (fixed child order, every way up
+// re-reads nodes) and meant for the rare ray only.  Returns true when an any-hit query has its answer.
+__device__ __forceinline__ bool trav_stackless(const DevScene& S, Trav& T, bool any)
+{
+    int cur = 0, k = 0;
+    for (long long guard = 6ll * S.n_prims + 16; guard > 0; --guard) {
+        const float4* n = S.bvh + 4 * (size_t)cur;
+        if (k == 2) {
+            if (cur == 0) break;
+            const int p = __float_as_int(n[3].z);
+            k = __float_as_int(S.bvh[4 * (size_t)p + 3].y) == cur ? 2 : 1;
+            cur = p;
+            continue;
+        }
+        const float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
+        const f3 lo = k ? mk3(n1.z, n1.w, n2.x) : mk3(n0.x, n0.y, n0.z);
+        const f3 hi = k ? mk3(n2.y, n2.z, n2.w) : mk3(n0.w, n1.x, n1.y);
+        const int code = __float_as_int(k ? n3.y : n3.x);
+        float tn;
+        count_lanes(S, 6);
+        if (slab_test(lo, hi, T.o, T.inv, trav_limit(T), tn)) {
+            if (code < 0) {
+                T.node = code;
+                if (trav_leaf(S, T, any)) return true;
+                ++k;
+            } else {
+                cur = code; k = 0;
+            }
+        } else {
+            ++k;
+        }
+    }
+    return false;
+}
+
+// Stack-based traversal of the 4-wide tree, one ray per lane.  One inner step loads one 128-byte
+// node and tests its four child boxes; the hit children are visited nearest first, the others
+// wait on the lane's stack in LDS and are dropped at pop time when a closer hit has been found
+// since.  The result does not depend on the visiting order because candidates are ranked by (t, id).
+__device__ __forceinline__ Hit intersect_bvh4(const DevScene& S, f3 o, f3 d, float maxd, float tlim, int skip, bool any)
+{
+    unsigned long long* my_lds = g_lds_stack + threadIdx.x;
+    Trav T;
+    trav_begin(T, o, d, maxd, tlim, skip);
+    if (is_zero3(d)) return T.best;
+    if (trav_big(S, T, any)) return T.best;
     // every node is entered at most once; the bound only guards against a corrupt tree
-    for (int guard = (VRT_LEAF_BATCH ? 64 : 1) * (2 * S.n_prims + 8); guard > 0 && !done; --guard) {
+    for (int guard = 2 * S.n_prims + 8; guard > 0; --guard) {
+        bool pop;
+        if (T.node >= 0) pop = trav_inner(S, T, my_lds, any);
+        else { if (trav_leaf(S, T, any)) return T.best; pop = true; }
+        if (pop && !trav_pop(T, my_lds)) break;
+    }
+    if (T.ovf) trav_stackless(S, T, any);
+    return T.best;
+}
+
+// Wave-uniform traversal of the 4-wide tree for rays a wave casts together and that stay close
+// to each other (the camera rays of one or a few pixels, the shadow and ambient-occlusion rays of
+// their hits): all calling lanes walk the same nodes.  The node index is wave-uniform, so a node
+// comes through the scalar cache into scalar registers (no vector-memory traffic at all), the
+// choice of the next node is scalar arithmetic, and a leaf's primitive is loaded once for the
+// wave.  A child is entered when ANY lane's ray passes its box; the stack holds, per lane, that
+// lane's entry distance next to the (uniform) child code, so an entry is skipped at pop time
+// once no lane can still gain from it.  Lanes test every primitive the wave reaches and rank
+// candidates by (t, id), so each lane ends with exactly the hit its own traversal would find.
+// Returns false (T untouched apart from the stack) when the wave's stack overflowed; the caller
+// then runs the per-lane traversal.
+__device__ __forceinline__ bool intersect_bvh4_packet(const DevScene& S, Trav& T, bool live, bool any)
+{
+    unsigned long long* my_lds = g_lds_stack + threadIdx.x;
+    Hit best = T.best;
+    bool found = !live;          // an any-hit lane that has its answer, or a lane without a ray
+    int sp = 0;                  // wave-uniform
+    int node = 0;                // wave-uniform
+    for (int guard = 4 * S.n_prims + 16; guard > 0; --guard) {
         bool pop = true;
-#if VRT_LEAF_BATCH
-        // A lane that holds a leaf waits until VRT_LEAF_BATCH lanes of the wave do, or until no
-        // lane has an inner node left: the primitive test then runs for many lanes at once
-        // instead of once per step for a few.
-        const bool leaf_now = __popcll(__ballot(node < 0)) >= VRT_LEAF_BATCH || !__any(node >= 0);
-#else
-        const bool leaf_now = true;
-#endif
         if (node >= 0) {
             count_lanes(S, 6);
-            float4 lx, ly, lz, hx, hy, hz, cc;
-#if VRT_LDS_TOP
-            if (node >= VRT_TOP_BASE) {
-                const float4* n = g_lds_top + 8 * (node - VRT_TOP_BASE);
-                lx = n[0]; ly = n[1]; lz = n[2]; hx = n[3]; hy = n[4]; hz = n[5]; cc = n[6];
-            } else
-#endif
-            {
-                const float4* n = S.bvh4 + 8 * (size_t)node;
-#if VRT_SIGN_SLAB
-                lx = n[rnx]; ly = n[rny]; lz = n[rnz]; hx = n[rnx ^ 3]; hy = n[rny ^ 5]; hz = n[rnz ^ 7]; cc = n[6];
-#else
-                lx = n[0]; ly = n[1]; lz = n[2]; hx = n[3]; hy = n[4]; hz = n[5]; cc = n[6];
-#endif
-            }
-            const float lim = best.prim >= 0 ? best.t : lim0;
-            int c0 = __float_as_int(cc.x), c1 = __float_as_int(cc.y), c2 = __float_as_int(cc.z), c3 = __float_as_int(cc.w);
-            float t0, t1, t2, t3;
-            bool h0, h1, h2, h3;
-            {   // the four slab tests of slab_test(), children (0,1) and (2,3) as packed pairs
-                const v2f ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
-                const v2f ix = {inv.x, inv.x}, iy = {inv.y, inv.y}, iz = {inv.z, inv.z};
-                const v2f ax01 = (v2f{lx.x, lx.y} - ox) * ix, ax23 = (v2f{lx.z, lx.w} - ox) * ix;
-                const v2f bx01 = (v2f{hx.x, hx.y} - ox) * ix, bx23 = (v2f{hx.z, hx.w} - ox) * ix;
-                const v2f ay01 = (v2f{ly.x, ly.y} - oy) * iy, ay23 = (v2f{ly.z, ly.w} - oy) * iy;
-                const v2f by01 = (v2f{hy.x, hy.y} - oy) * iy, by23 = (v2f{hy.z, hy.w} - oy) * iy;
-                const v2f az01 = (v2f{lz.x, lz.y} - oz) * iz, az23 = (v2f{lz.z, lz.w} - oz) * iz;
-                const v2f bz01 = (v2f{hz.x, hz.y} - oz) * iz, bz23 = (v2f{hz.z, hz.w} - oz) * iz;
-#if VRT_SIGN_SLAB   // A* = entry side, B* = exit side
-#define VRT_SLAB4(T, H, AX, BX, AY, BY, AZ, BZ)                                                       \
-                {                                                                                     \
-                    float n_ = fmaxf(fmaxf(AX, AY), fmaxf(AZ, 0.f));                                  \
-                    float f_ = fminf(fminf(BX, BY), fminf(BZ, lim));                                  \
-                    T = n_; H = n_ <= f_ * 1.0000004f;                                                \
+            const float4* n = S.bvh4 + 8 * (size_t)node;
+            const float4 lx = n[0], ly = n[1], lz = n[2], hx = n[3], hy = n[4], hz = n[5], cc = n[6];
+            const float lim = found ? -INFINITY : (best.prim >= 0 ? best.t : T.lim0);
+            const Slab4 r = slab4(lx, ly, lz, hx, hy, hz, T.o, T.inv, lim);
+            const unsigned long long m0 = __ballot(r.h0), m1 = __ballot(r.h1), m2 = __ballot(r.h2), m3 = __ballot(r.h3);
+            // order key of a child: entry distance of the first lane that passes its box (bits of a
+            // non-negative float compare like integers); no lane: never entered
+            const int k0 = m0 ? __builtin_amdgcn_readlane(__float_as_int(r.t0), __ffsll((long long)m0) - 1) : 0x7fffffff;
+            const int k1 = m1 ? __builtin_amdgcn_readlane(__float_as_int(r.t1), __ffsll((long long)m1) - 1) : 0x7fffffff;
+            const int k2 = m2 ? __builtin_amdgcn_readlane(__float_as_int(r.t2), __ffsll((long long)m2) - 1) : 0x7fffffff;
+            const int k3 = m3 ? __builtin_amdgcn_readlane(__float_as_int(r.t3), __ffsll((long long)m3) - 1) : 0x7fffffff;
+            int first = 0, kmin = k0;
+            if (k1 < kmin) { kmin = k1; first = 1; }
+            if (k2 < kmin) { kmin = k2; first = 2; }
+            if (k3 < kmin) { kmin = k3; first = 3; }
+            if (kmin != 0x7fffffff) {
+                pop = false;
+                const int n_push = (m0 != 0) + (m1 != 0) + (m2 != 0) + (m3 != 0) - 1;
+                if (sp + n_push > VRT_TRAV_STACK) return false;
+#define VRT_PPUSH(I, M, H, TT, C)                                                                           \
+                if (first != I && M) {                                                                      \
+                    my_lds[sp * VRT_STACK_LANES] =                                                          \
+                        ((unsigned long long)__float_as_uint(H ? TT : INFINITY) << 32) | (unsigned)__float_as_int(C); \
+                    ++sp;                                                                                   \
                 }
-#else
-#define VRT_SLAB4(T, H, AX, BX, AY, BY, AZ, BZ)                                                       \
-                {                                                                                     \
-                    float n_ = fmaxf(fmaxf(fminf(AX, BX), fminf(AY, BY)), fmaxf(fminf(AZ, BZ), 0.f)); \
-                    float f_ = fminf(fminf(fmaxf(AX, BX), fmaxf(AY, BY)), fminf(fmaxf(AZ, BZ), lim)); \
-                    T = n_; H = n_ <= f_ * 1.0000004f;                                                \
-                }
-#endif
-                VRT_SLAB4(t0, h0, ax01.x, bx01.x, ay01.x, by01.x, az01.x, bz01.x)
-                VRT_SLAB4(t1, h1, ax01.y, bx01.y, ay01.y, by01.y, az01.y, bz01.y)
-                VRT_SLAB4(t2, h2, ax23.x, bx23.x, ay23.x, by23.x, az23.x, bz23.x)
-                VRT_SLAB4(t3, h3, ax23.y, bx23.y, ay23.y, by23.y, az23.y, bz23.y)
-#undef VRT_SLAB4
+                VRT_PPUSH(3, m3, r.h3, r.t3, cc.w) VRT_PPUSH(2, m2, r.h2, r.t2, cc.z)
+                VRT_PPUSH(1, m1, r.h1, r.t1, cc.y) VRT_PPUSH(0, m0, r.h0, r.t0, cc.x)
+#undef VRT_PPUSH
+                const int cf = first == 0 ? __float_as_int(cc.x) : first == 1 ? __float_as_int(cc.y)
+                             : first == 2 ? __float_as_int(cc.z) : __float_as_int(cc.w);
+                node = __builtin_amdgcn_readfirstlane(cf);
             }
-#define VRT_PUSH4(T, C)                                                                              \
-            {                                                                                        \
-                unsigned long long e_ = ((unsigned long long)__float_as_uint(T) << 32) | (unsigned)(C); \
-                if (sp < VRT_LDS_STACK4) my_lds[sp * VRT_STACK_LANES] = e_;                          \
-                else if (sp < VRT_BVH4_STACK) deep[sp - VRT_LDS_STACK4] = e_;                        \
-                sp++;                                                                                \
-            }
-            // unused slots hold boxes at +inf, which no ray passes
-            if (ANY) {
-                // any-hit: the visiting order is irrelevant; the first hit child is entered, the
-                // others wait with distance 0 (never dropped at pop time)
-                bool taken = false;
-#define VRT_VISIT_ANY(H, C) if (H) { if (!taken) { node = C; taken = true; } else VRT_PUSH4(0.f, C) }
-                VRT_VISIT_ANY(h0, c0) VRT_VISIT_ANY(h1, c1) VRT_VISIT_ANY(h2, c2) VRT_VISIT_ANY(h3, c3)
-#undef VRT_VISIT_ANY
-                pop = !taken;
-            } else {
-                t0 = h0 ? t0 : INFINITY;
-                t1 = h1 ? t1 : INFINITY;
-                t2 = h2 ? t2 : INFINITY;
-                t3 = h3 ? t3 : INFINITY;
-                order2(t0, c0, t1, c1); order2(t2, c2, t3, c3);
-                order2(t0, c0, t2, c2); order2(t1, c1, t3, c3);
-                order2(t1, c1, t2, c2);
-                if (t0 < INFINITY) {
-                    node = c0;
-                    pop = false;
-                    if (t3 < INFINITY) VRT_PUSH4(t3, c3)
-                    if (t2 < INFINITY) VRT_PUSH4(t2, c2)
-                    if (t1 < INFINITY) VRT_PUSH4(t1, c1)
-                }
-            }
-#undef VRT_PUSH4
-        } else if (leaf_now) {
-            int id = ~node;
-            count_lanes(S, 7);
-            if (id != skip) test_prim(S, id, o, d, maxd, best);
-            if (ANY && best.prim >= 0) { if (best.t < tlim) return best; best.prim = -1; best.t = INFINITY; }
         } else {
-            pop = false;
+            const int id = ~node;
+            count_lanes(S, 7);
+            if (!found && id != T.skip) test_prim(S, id, T.o, T.d, T.maxd, best);
+            if (any && !found && best.prim >= 0) {
+                if (best.t < T.tlim) found = true;
+                else { best.prim = -1; best.t = INFINITY; }
+            }
+            if (any && !__any(!found)) break;   // every lane has its answer
         }
         if (pop) {
-            const float lim = best.prim >= 0 ? best.t : lim0;
-            for (;;) {
-                if (sp == 0) { done = true; break; }
+            const float lim = found ? -INFINITY : (best.prim >= 0 ? best.t : T.lim0);
+            bool got = false;
+            while (sp > 0) {
                 --sp;
-                unsigned long long e = sp < VRT_LDS_STACK4 ? my_lds[sp * VRT_STACK_LANES]
-                                                          : deep[(sp < VRT_BVH4_STACK ? sp : VRT_BVH4_STACK - 1) - VRT_LDS_STACK4];
-                if (!(__uint_as_float((unsigned)(e >> 32)) > lim)) { node = (int)(unsigned)e; break; }
+                const unsigned long long e = my_lds[sp * VRT_STACK_LANES];
+                if (__any(!(__uint_as_float((unsigned)(e >> 32)) > lim))) {
+                    node = __builtin_amdgcn_readfirstlane((int)(unsigned)e);
+                    got = true;
+                    break;
+                }
             }
+            if (!got) break;
         }
     }
-    return best;
+    T.best = best;
+    return true;
 }
 
 // Closest hit (ANY = false) or "some hit with t < tlim" (ANY = true) within maxd.
 template <bool BVH, bool ANY, bool CAM = false>
 __device__ __forceinline__ Hit intersect(const DevScene& S, f3 o, f3 d, float maxd, int skip, float tlim = INFINITY)
 {
-    if (BVH) return VRT_BVH4 ? intersect_bvh4(S, o, d, maxd, tlim, skip, ANY) : intersect_bvh(S, o, d, maxd, tlim, skip, ANY);
+    if (BVH) return intersect_bvh4(S, o, d, maxd, tlim, skip, ANY);
     return intersect_brute<CAM>(S, o, d, maxd, tlim, skip, ANY);
 }
 
@@ -580,7 +626,7 @@ __device__ __forceinline__ Hit intersect(const DevScene& S, f3 o, f3 d, float ma
 template <bool BVH>
 __device__ __forceinline__ Hit intersect_rt(const DevScene& S, f3 o, f3 d, float maxd, int skip, float tlim, bool any)
 {
-    if (BVH) return VRT_BVH4 ? intersect_bvh4(S, o, d, maxd, tlim, skip, any) : intersect_bvh(S, o, d, maxd, tlim, skip, any);
+    if (BVH) return intersect_bvh4(S, o, d, maxd, tlim, skip, any);
     return intersect_brute<false>(S, o, d, maxd, tlim, skip, any);
 }
 
@@ -623,6 +669,48 @@ __device__ __forceinline__ void count_event(int k)
 #else
 #define VRT_COUNT(C, FIELD, K) ((C).FIELD++)
 #endif
+
+// Global row of local row r of a strip-sharded frame (vrt_params.tile_*).
+__device__ __forceinline__ int local_to_global_row(const DevParams& P, int r)
+{
+    if (P.tile_count <= 1) return r;
+    return ((r / P.tile_rows) * P.tile_count + P.tile_index) * P.tile_rows + (r % P.tile_rows);
+}
+
+__device__ __forceinline__ unsigned wave_sum(unsigned v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Adds this block's counters into one of VRT_CTR_SLOTS slots (one atomic per class per block).
+__device__ __forceinline__ void flush_counters(const Counters& C, unsigned long long* ctr, unsigned block_linear)
+{
+#if VRT_LDS_COUNTERS
+    __syncthreads();   // counts were added to g_lds_ctr as the rays were cast
+    if (threadIdx.x < VRT_RAY_CLASSES && g_lds_ctr[threadIdx.x])
+        atomicAdd(&ctr[(block_linear % VRT_CTR_SLOTS) * VRT_CTR_STRIDE + threadIdx.x],
+                  (unsigned long long)g_lds_ctr[threadIdx.x]);
+#else
+    __shared__ unsigned s_ctr[VRT_RAY_CLASSES];
+    if (threadIdx.x < VRT_RAY_CLASSES) s_ctr[threadIdx.x] = 0;
+    __syncthreads();
+    // one field at a time: an indexed local array of the six counts would live in scratch
+#define VRT_FLUSH(K, FIELD)                                               \
+    {                                                                     \
+        unsigned s = wave_sum(C.FIELD);                                   \
+        if ((threadIdx.x & 63) == 0 && s) atomicAdd(&s_ctr[K], s);        \
+    }
+    VRT_FLUSH(VRT_RAY_PRECHECK, precheck) VRT_FLUSH(VRT_RAY_PRIMARY, primary) VRT_FLUSH(VRT_RAY_REFLECT, reflect)
+    VRT_FLUSH(VRT_RAY_TRANSMIT, transmit) VRT_FLUSH(VRT_RAY_SHADOW, shadow) VRT_FLUSH(VRT_RAY_AO, ao)
+#undef VRT_FLUSH
+    __syncthreads();
+    if (threadIdx.x < VRT_RAY_CLASSES && s_ctr[threadIdx.x])
+        atomicAdd(&ctr[(block_linear % VRT_CTR_SLOTS) * VRT_CTR_STRIDE + threadIdx.x],
+                  (unsigned long long)s_ctr[threadIdx.x]);
+#endif
+}
 
 struct Recorder {
     vrt_path_seg* segs; // null = off

@@ -32,46 +32,6 @@
 
 namespace {
 
-__device__ __forceinline__ int local_to_global_row(const DevParams& P, int r)
-{
-    if (P.tile_count <= 1) return r;
-    return ((r / P.tile_rows) * P.tile_count + P.tile_index) * P.tile_rows + (r % P.tile_rows);
-}
-
-__device__ __forceinline__ unsigned wave_sum(unsigned v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-
-__device__ __forceinline__ void flush_counters(const Counters& C, unsigned long long* ctr, unsigned block_linear)
-{
-#if VRT_LDS_COUNTERS
-    __syncthreads();   // counts were added to g_lds_ctr as the rays were cast
-    if (threadIdx.x < VRT_RAY_CLASSES && g_lds_ctr[threadIdx.x])
-        atomicAdd(&ctr[(block_linear % VRT_CTR_SLOTS) * VRT_CTR_STRIDE + threadIdx.x],
-                  (unsigned long long)g_lds_ctr[threadIdx.x]);
-    return;
-#endif
-    __shared__ unsigned s_ctr[VRT_RAY_CLASSES];
-    if (threadIdx.x < VRT_RAY_CLASSES) s_ctr[threadIdx.x] = 0;
-    __syncthreads();
-    // one field at a time: an indexed local array of the six counts would live in scratch
-#define VRT_FLUSH(K, FIELD)                                               \
-    {                                                                     \
-        unsigned s = wave_sum(C.FIELD);                                   \
-        if ((threadIdx.x & 63) == 0 && s) atomicAdd(&s_ctr[K], s);        \
-    }
-    VRT_FLUSH(VRT_RAY_PRECHECK, precheck) VRT_FLUSH(VRT_RAY_PRIMARY, primary) VRT_FLUSH(VRT_RAY_REFLECT, reflect)
-    VRT_FLUSH(VRT_RAY_TRANSMIT, transmit) VRT_FLUSH(VRT_RAY_SHADOW, shadow) VRT_FLUSH(VRT_RAY_AO, ao)
-#undef VRT_FLUSH
-    __syncthreads();
-    if (threadIdx.x < VRT_RAY_CLASSES && s_ctr[threadIdx.x])
-        atomicAdd(&ctr[(block_linear % VRT_CTR_SLOTS) * VRT_CTR_STRIDE + threadIdx.x],
-                  (unsigned long long)s_ctr[threadIdx.x]);
-}
-
 // Slot for this lane's ray in the output queue, or -1.  Must be called by the whole wave.
 __device__ __forceinline__ int wave_append(bool want, int* counter, int cap, int* overflow)
 {
@@ -238,7 +198,7 @@ __global__ __launch_bounds__(256, 4) void k_wf_primary(DevScene S, DevCam cam, D
     const int r = row0 + rb;
     const int h = local_to_global_row(P, r);
     const bool inside = tile < n_tiles && v < cam.width && rb < band_rows && r < P.local_rows && h < cam.height;
-    if (BVH) stage_bvh_top(S); else stage_prims(S);
+    if (!BVH) stage_prims(S);
     Counters C = {0, 0, 0, 0, 0, 0};
 #if VRT_LDS_COUNTERS
     if (threadIdx.x < VRT_RAY_CLASSES) g_lds_ctr[threadIdx.x] = 0;
@@ -286,7 +246,7 @@ __global__ __launch_bounds__(256, VRT_WF_BOUNCE_BLOCKS) void k_wf_bounce(DevScen
     const RayQueue& in = W.q[(depth - 1) & 1];
     int count = W.counts[depth - 1];
     if (count > (int)W.cap) count = (int)W.cap;
-    if (BVH) stage_bvh_top(S); else stage_prims(S);
+    if (!BVH) stage_prims(S);
     Counters C = {0, 0, 0, 0, 0, 0};
 #if VRT_LDS_COUNTERS
     if (threadIdx.x < VRT_RAY_CLASSES) g_lds_ctr[threadIdx.x] = 0;
@@ -332,7 +292,7 @@ __global__ __launch_bounds__(256, VRT_WF_BOUNCE_BLOCKS) void k_wf_bounce_a(DevSc
     const RayQueue& in = W.q[(depth - 1) & 1];
     int count = W.counts[depth - 1];
     if (count > (int)W.cap) count = (int)W.cap;
-    if (BVH) stage_bvh_top(S); else stage_prims(S);
+    if (!BVH) stage_prims(S);
     Counters C = {0, 0, 0, 0, 0, 0};
 #if VRT_LDS_COUNTERS
     if (threadIdx.x < VRT_RAY_CLASSES) g_lds_ctr[threadIdx.x] = 0;
@@ -375,7 +335,7 @@ __global__ __launch_bounds__(256, VRT_WF_BOUNCE_BLOCKS) void k_wf_any(DevScene S
 {
     int count = W.any_counts[depth];
     if (count > (int)W.any_cap) count = (int)W.any_cap;
-    if (BVH) stage_bvh_top(S); else stage_prims(S);
+    if (!BVH) stage_prims(S);
     const AnyQueue& q = W.any;
     const int stride = gridDim.x * 256;
     for (int j = blockIdx.x * 256 + threadIdx.x; j < count; j += stride) {
@@ -402,15 +362,10 @@ __global__ __launch_bounds__(256, VRT_WF_BOUNCE_BLOCKS) void k_wf_any(DevScene S
 #define VRT_WF_REFILL 16
 #endif
 #define VRT_WF_TRACE_CHUNK 256
-#ifndef VRT_WF_TRACE_LDS
-#define VRT_WF_TRACE_LDS 8    // stack entries per lane in LDS: 16 KB per block, so that registers (60) bound the occupancy
-#endif
 template <bool ANY>
 __global__ __launch_bounds__(256, VRT_WF_BOUNCE_BLOCKS) void k_wf_trace(DevScene S, DevParams P, WfWorkspace W, int depth)
 {
-    __shared__ unsigned long long lds_stack[VRT_WF_TRACE_LDS * 256];
-    unsigned long long* my_lds = lds_stack + threadIdx.x;
-    unsigned long long deep[VRT_BVH4_STACK - VRT_WF_TRACE_LDS];
+    unsigned long long* my_lds = g_lds_stack + threadIdx.x;
     const RayQueue& in = W.q[(depth - 1) & 1];
     const AnyQueue& q = W.any;
     int count = ANY ? W.any_counts[depth] : W.counts[depth - 1];
@@ -422,10 +377,9 @@ __global__ __launch_bounds__(256, VRT_WF_BOUNCE_BLOCKS) void k_wf_trace(DevScene
     bool exhausted = count <= 0;      // wave-uniform: the cursor has passed the end of the queue
     bool first = true;                // wave-uniform: no chunk taken yet
     bool have = false;                // this lane is in the middle of a traversal
-    f3 o = mk3(0.f, 0.f, 0.f), d = o, inv = o;
-    float maxd = 0.f, tlim = 0.f, lim0 = 0.f;
-    int skip = -1, node = 0, sp = 0, entry = 0, bit = 0, steps_left = 0;
-    Hit best; best.t = INFINITY; best.prim = -1; best.aux = 0;
+    Trav T;
+    trav_begin(T, mk3(0.f, 0.f, 0.f), mk3(0.f, 0.f, 1.f), 0.f, 0.f, -1);
+    int entry = 0, bit = 0, steps_left = 0;
     for (;;) {
         const unsigned long long idle = __ballot(!have);
         if (!exhausted && __popcll(idle) >= VRT_WF_REFILL) {
@@ -453,6 +407,9 @@ __global__ __launch_bounds__(256, VRT_WF_BOUNCE_BLOCKS) void k_wf_trace(DevScene
                 if (!have && r < take) {
                     entry = next + r;
                     bool valid;
+                    f3 o = mk3(0.f, 0.f, 0.f), d = o;
+                    float maxd = 0.f, tlim = 0.f;
+                    int skip = -1;
                     if (ANY) {
                         const int target = q.target[entry];
                         valid = target >= 0 && target < (int)W.cap;   // else: entry of a chunk nobody filled
@@ -472,27 +429,17 @@ __global__ __launch_bounds__(256, VRT_WF_BOUNCE_BLOCKS) void k_wf_trace(DevScene
                         }
                     }
                     if (valid) {
-                        best.t = INFINITY; best.prim = -1; best.aux = 0;
+                        trav_begin(T, o, d, maxd, tlim, skip);
                         bool found = false;
                         have = !is_zero3(d);
                         if (have) {
-                            inv = mk3(1.f / d.x, 1.f / d.y, 1.f / d.z);
-                            lim0 = fminf(maxd, tlim);
-                            for (int k = 0; k < S.n_big; ++k) {   // scene-sized primitives kept out of the tree
-                                const int id = S.big[k];
-                                count_lanes(S, 7);
-                                if (id != skip) test_prim(S, id, o, d, maxd, best);
-                                if (ANY && best.prim >= 0) {
-                                    if (best.t < tlim) { found = true; break; }
-                                    best.prim = -1; best.t = INFINITY;
-                                }
-                            }
-                            node = 0; sp = 0; steps_left = 2 * S.n_prims + 8;
+                            found = trav_big(S, T, ANY);
+                            steps_left = 2 * S.n_prims + 8;
                             if (found) have = false;
                         }
                         if (!have) {
                             if (ANY) { if (found) atomicOr((unsigned*)&W.hits[entry].w, 1u << bit); }
-                            else W.hits[entry] = make_int4(__float_as_int(best.t), best.prim, best.aux, 0);
+                            else W.hits[entry] = make_int4(__float_as_int(T.best.t), T.best.prim, T.best.aux, 0);
                         }
                     }
                 }
@@ -504,89 +451,16 @@ __global__ __launch_bounds__(256, VRT_WF_BOUNCE_BLOCKS) void k_wf_trace(DevScene
             continue;
         }
         if (have) {
-            bool pop = true, finished = false, found = false;
-            if (node >= 0) {
-                count_lanes(S, 6);
-                const float4* n = S.bvh4 + 8 * (size_t)node;
-                const float4 lx = n[0], ly = n[1], lz = n[2], hx = n[3], hy = n[4], hz = n[5], cc = n[6];
-                const float lim = best.prim >= 0 ? best.t : lim0;
-                int c0 = __float_as_int(cc.x), c1 = __float_as_int(cc.y), c2 = __float_as_int(cc.z), c3 = __float_as_int(cc.w);
-                float t0, t1, t2, t3;
-                bool h0, h1, h2, h3;
-                {
-                    const v2f ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
-                    const v2f ix = {inv.x, inv.x}, iy = {inv.y, inv.y}, iz = {inv.z, inv.z};
-                    const v2f ax01 = (v2f{lx.x, lx.y} - ox) * ix, ax23 = (v2f{lx.z, lx.w} - ox) * ix;
-                    const v2f bx01 = (v2f{hx.x, hx.y} - ox) * ix, bx23 = (v2f{hx.z, hx.w} - ox) * ix;
-                    const v2f ay01 = (v2f{ly.x, ly.y} - oy) * iy, ay23 = (v2f{ly.z, ly.w} - oy) * iy;
-                    const v2f by01 = (v2f{hy.x, hy.y} - oy) * iy, by23 = (v2f{hy.z, hy.w} - oy) * iy;
-                    const v2f az01 = (v2f{lz.x, lz.y} - oz) * iz, az23 = (v2f{lz.z, lz.w} - oz) * iz;
-                    const v2f bz01 = (v2f{hz.x, hz.y} - oz) * iz, bz23 = (v2f{hz.z, hz.w} - oz) * iz;
-#define VRT_SLAB4(T, H, AX, BX, AY, BY, AZ, BZ)                                                       \
-                    {                                                                                 \
-                        float n_ = fmaxf(fmaxf(fminf(AX, BX), fminf(AY, BY)), fmaxf(fminf(AZ, BZ), 0.f)); \
-                        float f_ = fminf(fminf(fmaxf(AX, BX), fmaxf(AY, BY)), fminf(fmaxf(AZ, BZ), lim)); \
-                        T = n_; H = n_ <= f_ * 1.0000004f;                                            \
-                    }
-                    VRT_SLAB4(t0, h0, ax01.x, bx01.x, ay01.x, by01.x, az01.x, bz01.x)
-                    VRT_SLAB4(t1, h1, ax01.y, bx01.y, ay01.y, by01.y, az01.y, bz01.y)
-                    VRT_SLAB4(t2, h2, ax23.x, bx23.x, ay23.x, by23.x, az23.x, bz23.x)
-                    VRT_SLAB4(t3, h3, ax23.y, bx23.y, ay23.y, by23.y, az23.y, bz23.y)
-#undef VRT_SLAB4
-                }
-#define VRT_PUSH4(T, C)                                                                              \
-                {                                                                                    \
-                    unsigned long long e_ = ((unsigned long long)__float_as_uint(T) << 32) | (unsigned)(C); \
-                    if (sp < VRT_WF_TRACE_LDS) my_lds[sp * 256] = e_;                                  \
-                    else if (sp < VRT_BVH4_STACK) deep[sp - VRT_WF_TRACE_LDS] = e_;                    \
-                    sp++;                                                                            \
-                }
-                if (ANY) {
-                    bool taken = false;
-#define VRT_VISIT_ANY(H, C) if (H) { if (!taken) { node = C; taken = true; } else VRT_PUSH4(0.f, C) }
-                    VRT_VISIT_ANY(h0, c0) VRT_VISIT_ANY(h1, c1) VRT_VISIT_ANY(h2, c2) VRT_VISIT_ANY(h3, c3)
-#undef VRT_VISIT_ANY
-                    pop = !taken;
-                } else {
-                    t0 = h0 ? t0 : INFINITY;
-                    t1 = h1 ? t1 : INFINITY;
-                    t2 = h2 ? t2 : INFINITY;
-                    t3 = h3 ? t3 : INFINITY;
-                    order2(t0, c0, t1, c1); order2(t2, c2, t3, c3);
-                    order2(t0, c0, t2, c2); order2(t1, c1, t3, c3);
-                    order2(t1, c1, t2, c2);
-                    if (t0 < INFINITY) {
-                        node = c0;
-                        pop = false;
-                        if (t3 < INFINITY) VRT_PUSH4(t3, c3)
-                        if (t2 < INFINITY) VRT_PUSH4(t2, c2)
-                        if (t1 < INFINITY) VRT_PUSH4(t1, c1)
-                    }
-                }
-#undef VRT_PUSH4
-            } else {
-                const int id = ~node;
-                count_lanes(S, 7);
-                if (id != skip) test_prim(S, id, o, d, maxd, best);
-                if (ANY && best.prim >= 0) {
-                    if (best.t < tlim) found = finished = true;
-                    else { best.prim = -1; best.t = INFINITY; }
-                }
-            }
-            if (!finished && pop) {
-                const float lim = best.prim >= 0 ? best.t : lim0;
-                for (;;) {
-                    if (sp == 0) { finished = true; break; }
-                    --sp;
-                    unsigned long long e = sp < VRT_WF_TRACE_LDS ? my_lds[sp * 256]
-                                                              : deep[(sp < VRT_BVH4_STACK ? sp : VRT_BVH4_STACK - 1) - VRT_WF_TRACE_LDS];
-                    if (!(__uint_as_float((unsigned)(e >> 32)) > lim)) { node = (int)(unsigned)e; break; }
-                }
-            }
+            // one step of intersect_bvh4's loop
+            bool pop, finished = false, found = false;
+            if (T.node >= 0) pop = trav_inner(S, T, my_lds, ANY);
+            else { found = finished = trav_leaf(S, T, ANY); pop = true; }
+            if (!finished && pop && !trav_pop(T, my_lds)) finished = true;
             if (--steps_left <= 0) finished = true;   // only with a corrupt tree
             if (finished) {
+                if (!found && T.ovf) found = trav_stackless(S, T, ANY);
                 if (ANY) { if (found) atomicOr((unsigned*)&W.hits[entry].w, 1u << bit); }
-                else W.hits[entry] = make_int4(__float_as_int(best.t), best.prim, best.aux, 0);
+                else W.hits[entry] = make_int4(__float_as_int(T.best.t), T.best.prim, T.best.aux, 0);
                 have = false;
             }
         }

@@ -38,6 +38,18 @@ def load_library():
     L.vrt_abi_version.restype = C.c_int
     L.vrt_create.restype = C.c_int
     L.vrt_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.vrt_create_multi.restype = C.c_int
+    L.vrt_create_multi.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(vp)]
+    L.vrt_set_option.restype = C.c_int
+    L.vrt_set_option.argtypes = [vp, C.c_char_p, C.c_longlong]
+    L.vrt_host_register.restype = C.c_int
+    L.vrt_host_register.argtypes = [vp, vp, C.c_uint64]
+    L.vrt_host_unregister.restype = C.c_int
+    L.vrt_host_unregister.argtypes = [vp, vp]
+    L.vrt_render_begin_parts.restype = C.c_int
+    L.vrt_render_begin_parts.argtypes = [vp, C.POINTER(abi.vrt_params), vp, vp, C.c_int]
+    L.vrt_render_poll_parts.restype = C.c_int
+    L.vrt_render_poll_parts.argtypes = [vp, C.POINTER(C.c_int)]
     L.vrt_destroy.restype = C.c_int
     L.vrt_destroy.argtypes = [vp]
     L.vrt_last_error.restype = C.c_char_p
@@ -98,16 +110,23 @@ def pixel_set(seed, pixel, n_sets):
 
 
 class Context:
-    """One vrt_ctx on one GPU."""
+    """One vrt_ctx: on one GPU (device=ordinal) or on several GPUs of the node (devices=list of
+    ordinals, vrt_create_multi)."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, devices=None):
         self._lib = load_library()
         self._h = C.c_void_p()
-        rc = self._lib.vrt_create(device, C.byref(self._h))
+        if devices is not None:
+            arr = (C.c_int * len(devices))(*devices)
+            rc = self._lib.vrt_create_multi(len(devices), arr, C.byref(self._h))
+            device = devices[0] if len(devices) else 0
+        else:
+            rc = self._lib.vrt_create(device, C.byref(self._h))
         if rc != 0:
             self._h = None
             raise VrtError(rc, "vrt_create failed (no usable HIP device?)")
         self.device = device
+        self.devices = list(devices) if devices is not None else None
         self._scene = None
         self.cam = None
 
@@ -126,6 +145,17 @@ class Context:
         if rc != 0:
             raise VrtError(rc, self._lib.vrt_last_error(self._h).decode())
 
+    def set_option(self, name, value):
+        """Study/test knob by name (vrt_set_option); none changes a result."""
+        self._chk(self._lib.vrt_set_option(self._h, name.encode(), int(value)))
+
+    def host_register(self, array):
+        """Page-locks a numpy array that will receive frames (vrt_host_register)."""
+        self._chk(self._lib.vrt_host_register(self._h, array.ctypes.data, array.nbytes))
+
+    def host_unregister(self, array):
+        self._chk(self._lib.vrt_host_unregister(self._h, array.ctypes.data))
+
     def set_scene(self, scene):
         d = scene.desc()
         self._chk(self._lib.vrt_set_scene(self._h, C.byref(d)))
@@ -135,22 +165,32 @@ class Context:
         self._chk(self._lib.vrt_set_camera(self._h, C.byref(cam)))
         self.cam = cam
 
-    def render(self, params, rgba=None, hit=None):
-        """Whole frame into host arrays. Returns (rgba[H,W,4], hit[H,W], vrt_stats)."""
+    def render(self, params, rgba=None, hit=None, want_hit=True):
+        """Whole frame into host arrays. Returns (rgba[H,W,4], hit[H,W] or None, vrt_stats)."""
         H, W = self.cam.height, self.cam.width
         if rgba is None:
             rgba = np.zeros((H, W, 4), np.float32)
-        if hit is None:
+        if hit is None and want_hit:
             hit = np.full((H, W), -1, np.int32)
         st = abi.vrt_stats()
         self._chk(self._lib.vrt_render(self._h, C.byref(params.c), rgba.ctypes.data,
-                                       hit.ctypes.data, C.byref(st)))
+                                       hit.ctypes.data if hit is not None else None, C.byref(st)))
         return rgba, hit, st
 
     def render_begin(self, params, rgba, hit=None):
         """Starts a frame into the given host arrays (keep them alive until render_end)."""
         self._chk(self._lib.vrt_render_begin(self._h, C.byref(params.c), rgba.ctypes.data,
                                              hit.ctypes.data if hit is not None else None))
+
+    def render_begin_parts(self, params, rgba, hit=None, n_parts=4):
+        """Starts a frame delivered in n_parts strip sets (keep the arrays alive until render_end)."""
+        self._chk(self._lib.vrt_render_begin_parts(self._h, C.byref(params.c), rgba.ctypes.data,
+                                                   hit.ctypes.data if hit is not None else None, n_parts))
+
+    def render_poll_parts(self):
+        n = C.c_int(0)
+        self._chk(self._lib.vrt_render_poll_parts(self._h, C.byref(n)))
+        return n.value
 
     def render_poll(self):
         done = C.c_int(0)

@@ -37,6 +37,12 @@ def default_shading():
     s.ao_min_amount[:] = (0.05, 0.05, 0.05, 1.0)
     s.ao_ls = 1.0
     s.ao_color[:] = (1.0, 1.0, 1.0, 1.0)
+    # Material/MatteMaterial.cs:14-15 (two default LambertianBRDFs); Material/TransparentMaterial.cs:10-25
+    # has no shipped constructor call: Phong base defaults plus host-chosen ks, exp, ior, kr, kt
+    s.matte_ka, s.matte_kd = 0.5, 0.5
+    s.transp_ka, s.transp_kd, s.transp_ks, s.transp_exp = 0.5, 0.5, 0.5, 2000.0
+    s.transp_ior, s.transp_kr, s.transp_kt = 1.5, 0.1, 0.9
+    s.transp_ray_dir[:] = (0.0, 0.0, 0.0)
     return s
 
 

@@ -32,3 +32,18 @@ def vrt_ctx():
     ctx = host.Context(0)
     yield ctx
     ctx.close()
+
+
+OPTION_DEFAULTS = dict(xcd_remap=0, sample_shift=-1, wf_defer=1, wf_refill=1, wf_max_slots=0, wf_any_cap=-1,
+                       builder=0, collapse_parity=0, no_big=0, packet=-1, fail_after_build=0)
+
+
+@pytest.fixture
+def vrt_opts(vrt_ctx):
+    """set(name, value) changes a study option of the shared context; every option is back at its
+    default when the test ends."""
+    def set_option(name, value):
+        vrt_ctx.set_option(name, value)
+    yield set_option
+    for k, v in OPTION_DEFAULTS.items():
+        vrt_ctx.set_option(k, v)

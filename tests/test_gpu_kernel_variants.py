@@ -1,8 +1,6 @@
 """Kernel organisation must not change results: the pixel x sample lane split of the megakernel,
 the world-axis box test and the general oriented-box test all have to agree with the oracle, and
 the lane split has to be invisible bit for bit."""
-import os
-
 import numpy as np
 import pytest
 
@@ -14,24 +12,14 @@ TOL = 1.0 / 255.0
 
 
 def _render_with_shift(ctx, prm, shift):
-    old = os.environ.get("VRT_SAMPLE_SHIFT")
-    try:
-        if shift is None:
-            os.environ.pop("VRT_SAMPLE_SHIFT", None)
-        else:
-            os.environ["VRT_SAMPLE_SHIFT"] = str(shift)
-        rgba, hit, st = ctx.render(prm)
-        return rgba.copy(), hit.copy(), np.array(st.rays[:], np.uint64)
-    finally:
-        if old is None:
-            os.environ.pop("VRT_SAMPLE_SHIFT", None)
-        else:
-            os.environ["VRT_SAMPLE_SHIFT"] = old
+    ctx.set_option("sample_shift", -1 if shift is None else shift)
+    rgba, hit, st = ctx.render(prm)
+    return rgba.copy(), hit.copy(), np.array(st.rays[:], np.uint64)
 
 
 @pytest.mark.parametrize("spp", [1, 3, 4, 16, 50])
 @pytest.mark.parametrize("bvh", [False, True])
-def test_sample_lane_split_is_bitwise_invisible(vrt_ctx, spp, bvh):
+def test_sample_lane_split_is_bitwise_invisible(vrt_ctx, vrt_opts, spp, bvh):
     """Every split of the 64 lanes into pixels x samples sums the samples in the same order, so
     frames, hit ids and ray counts are identical to one lane per pixel (odd frame sizes and
     sample counts that do not fill the lanes included)."""
@@ -112,7 +100,7 @@ def test_rays_along_box_edges_and_axes(vrt_ctx, oracle_mod):
 
 
 @pytest.mark.parametrize("spp", [1, 5, 16])
-def test_wavefront_bands_equal_megakernel(vrt_ctx, spp):
+def test_wavefront_bands_equal_megakernel(vrt_ctx, vrt_opts, spp):
     """The wavefront pipeline works through the frame in bands of rows that fit its sample-slot
     budget; with the budget forced down to a few rows the frame must still be the megakernel's
     bit for bit, strips and ragged last bands included."""
@@ -122,29 +110,22 @@ def test_wavefront_bands_equal_megakernel(vrt_ctx, spp):
     vrt_ctx.set_scene(scene)
     vrt_ctx.set_camera(cam)
     ref, ref_hit, ref_st = vrt_ctx.render(ra.Params(mode=abi.VRT_MODE_MEGAKERNEL, **kw))
-    old = os.environ.get("VRT_WF_MAX_SLOTS")
-    try:
-        for budget in (75 * spp * 8, 75 * spp * 19, 10 ** 9):
-            os.environ["VRT_WF_MAX_SLOTS"] = str(budget)
-            got, got_hit, st = vrt_ctx.render(ra.Params(mode=abi.VRT_MODE_WAVEFRONT, **kw))
-            assert st.mode_used == abi.VRT_MODE_WAVEFRONT
-            assert np.array_equal(got, ref, equal_nan=True) and np.array_equal(got_hit, ref_hit)
-            assert list(st.rays) == list(ref_st.rays)
-        os.environ["VRT_WF_MAX_SLOTS"] = str(75 * spp * 8)
-        rows = [h for h in range(53) if (h // 8) % 3 == 1]
-        out = np.zeros((len(rows), 75, 4), np.float32)
-        vrt_ctx.render(ra.Params(mode=abi.VRT_MODE_WAVEFRONT, tile_index=1, tile_count=3, tile_rows=8,
-                                 compact_rows=True, **kw), rgba=out, hit=np.zeros((len(rows), 75), np.int32))
-        assert np.array_equal(out, ref[rows], equal_nan=True)
-    finally:
-        if old is None:
-            os.environ.pop("VRT_WF_MAX_SLOTS", None)
-        else:
-            os.environ["VRT_WF_MAX_SLOTS"] = old
+    for budget in (75 * spp * 8, 75 * spp * 19, 10 ** 9):
+        vrt_opts("wf_max_slots", budget)
+        got, got_hit, st = vrt_ctx.render(ra.Params(mode=abi.VRT_MODE_WAVEFRONT, **kw))
+        assert st.mode_used == abi.VRT_MODE_WAVEFRONT
+        assert np.array_equal(got, ref, equal_nan=True) and np.array_equal(got_hit, ref_hit)
+        assert list(st.rays) == list(ref_st.rays)
+    vrt_opts("wf_max_slots", 75 * spp * 8)
+    rows = [h for h in range(53) if (h // 8) % 3 == 1]
+    out = np.zeros((len(rows), 75, 4), np.float32)
+    vrt_ctx.render(ra.Params(mode=abi.VRT_MODE_WAVEFRONT, tile_index=1, tile_count=3, tile_rows=8,
+                             compact_rows=True, **kw), rgba=out, hit=np.zeros((len(rows), 75), np.int32))
+    assert np.array_equal(out, ref[rows], equal_nan=True)
 
 
 @pytest.mark.parametrize("which", ["spheres", "mesh"])
-def test_frames_do_not_depend_on_the_tree(vrt_ctx, which):
+def test_frames_do_not_depend_on_the_tree(vrt_ctx, vrt_opts, which):
     """Closest hits are ranked by (t, id), so the builder (PLOC or the radix tree), the collapse
     (surface-area-guided or every second level) and keeping scene-sized primitives in or out of
     the tree must all give the same frame, hit ids and ray counts, bit for bit."""
@@ -153,26 +134,16 @@ def test_frames_do_not_depend_on_the_tree(vrt_ctx, which):
     else:
         scene, cam, rng = ra.tessellated_mesh_scene(quads=40), ra.tessellated_mesh_camera(120, 68), 100.0
     prm = ra.Params(spp=2, max_depth=5, rng=rng)
-    names = ("VRT_BUILDER", "VRT_COLLAPSE_PARITY", "VRT_NO_BIG")
-    old = {k: os.environ.get(k) for k in names}
+    names = ("builder", "collapse_parity", "no_big")
     results = []
-    try:
-        for env in ({}, {"VRT_BUILDER": "lbvh"}, {"VRT_COLLAPSE_PARITY": "1"},
-                    {"VRT_BUILDER": "lbvh", "VRT_COLLAPSE_PARITY": "1", "VRT_NO_BIG": "1"}):
-            for k in names:
-                os.environ.pop(k, None)
-            os.environ.update(env)
-            vrt_ctx.set_scene(scene)   # the tree is built here
-            vrt_ctx.set_camera(cam)
-            rgba, hit, st = vrt_ctx.render(prm)
-            assert st.bvh_nodes > 0
-            results.append((rgba.copy(), hit.copy(), list(st.rays)))
-    finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+    for opts in ({}, {"builder": 1}, {"collapse_parity": 1}, {"builder": 1, "collapse_parity": 1, "no_big": 1}):
+        for k in names:
+            vrt_opts(k, opts.get(k, 0))
+        vrt_ctx.set_scene(scene)   # the tree is built here
+        vrt_ctx.set_camera(cam)
+        rgba, hit, st = vrt_ctx.render(prm)
+        assert st.bvh_nodes > 0
+        results.append((rgba.copy(), hit.copy(), list(st.rays)))
     for r in results[1:]:
         assert np.array_equal(r[0], results[0][0], equal_nan=True)
         assert np.array_equal(r[1], results[0][1]) and r[2] == results[0][2]

@@ -51,17 +51,17 @@ def test_triangle_mesh_bvh(vrt_ctx, oracle_mod):
 
 @pytest.mark.parametrize("defer", ["deferred", "no_refill", "in_place", "short_queue"])
 @pytest.mark.parametrize("which", ["teaching", "spheres", "mesh"])
-def test_wavefront_equals_megakernel(vrt_ctx, oracle_mod, which, defer, monkeypatch):
+def test_wavefront_equals_megakernel(vrt_ctx, vrt_opts, oracle_mod, which, defer):
     """Bounce steps with rays and occlusion queries traced from queues by lanes that are refilled
     as they finish (the default on scenes with a tree), with one queue entry per lane and pass,
     with the queries traced where they arise, and with a queue too short for them (the rest is
     traced in place): all give the megakernel's bits and ray counts."""
     if defer == "no_refill":
-        monkeypatch.setenv("VRT_WF_REFILL", "0")
+        vrt_opts("wf_refill", 0)
     elif defer == "in_place":
-        monkeypatch.setenv("VRT_WF_DEFER", "0")
+        vrt_opts("wf_defer", 0)
     elif defer == "short_queue":
-        monkeypatch.setenv("VRT_WF_ANY_CAP", "1000")
+        vrt_opts("wf_any_cap", 1000)
     if which == "teaching":
         scene, cam, rng = ra.teaching_scene(), ra.teaching_camera(200, 120), 30.0
     elif which == "spheres":
