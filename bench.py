@@ -236,6 +236,8 @@ def main():
     ap.add_argument("--frames-8k", type=int, default=2,
                     help="frames of the 8K x 64 spp strong-scaling measurement reported as `scaling_8k` "
                          "(0 = skip it)")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="study option of the library (vrt_set_option), e.g. --opt packet=0")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -273,6 +275,9 @@ def main():
     prm = ra.Params(offsets=offsets, mode=mode, tile_index=rank, tile_count=world, tile_rows=args.tile_rows,
                     compact_rows=True, **prm_kw)
     ctx = host.Context(local_rank)
+    for o in args.opt:
+        name, _, value = o.partition("=")
+        ctx.set_option(name, int(value))
     ctx.set_scene(scene)
     ctx.set_camera(cam)
 

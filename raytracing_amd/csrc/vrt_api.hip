@@ -81,6 +81,7 @@ static void options_from_env(VrtOptions& o)
     o.collapse_parity = (int)geti("VRT_COLLAPSE_PARITY", 0);
     o.no_big = (int)geti("VRT_NO_BIG", 0);
     o.packet = (int)geti("VRT_PACKET", -1);
+    o.block_compact = (int)geti("VRT_BLOCK_COMPACT", 0);
 }
 
 extern "C" int vrt_set_option(vrt_ctx* c, const char* name, long long value)
@@ -98,8 +99,9 @@ extern "C" int vrt_set_option(vrt_ctx* c, const char* name, long long value)
     else if (n == "builder") o.builder_lbvh = value != 0;
     else if (n == "collapse_parity") o.collapse_parity = value != 0;
     else if (n == "no_big") o.no_big = value != 0;
+    else if (n == "block_compact") o.block_compact = value != 0;
     else if (n == "fail_after_build") o.fail_after_build = value != 0;
-    else if (n == "packet") { if (value < -1 || value > 1) return fail(c, VRT_ERR_INVALID, "packet: -1, 0 or 1"); o.packet = (int)value; }
+    else if (n == "packet") { if (value < -1 || value > 2) return fail(c, VRT_ERR_INVALID, "packet: -1, 0, 1 or 2"); o.packet = (int)value; }
     else return fail(c, VRT_ERR_INVALID, "unknown option " + n);
     if (c->multi) return vrt_multi_set_option(c, name, value);
     return VRT_OK;
@@ -751,7 +753,10 @@ static int enqueue_frame(vrt_ctx* c, const vrt_params* p, const DevParams& P, fl
             ctr = c->d_ctr_ring + (size_t)slot * kCtrBlock;
         }
         S.dbg = ctr; c->last_ctr = ctr;
-        HIPCHK(c, vrt_launch_mega(S, c->cam, P, c->sb.use_bvh, two, rgba, hit, ctr, stream));
+        if (c->sb.use_bvh && !two && !P.xcd_remap && c->opt.block_compact)
+            HIPCHK(c, vrt_launch_mega_blk(S, c->cam, P, rgba, hit, ctr, stream));
+        else
+            HIPCHK(c, vrt_launch_mega(S, c->cam, P, c->sb.use_bvh, two, rgba, hit, ctr, stream));
     }
     c->last_pixels = (uint64_t)P.local_rows * c->cam.width;
     c->last_mode = mode;

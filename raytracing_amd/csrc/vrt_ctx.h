@@ -10,7 +10,7 @@
 
 // Study and test knobs.  Environment variables of the same meaning (VRT_XCD_REMAP, VRT_SAMPLE_SHIFT,
 // VRT_WF_DEFER, VRT_WF_REFILL, VRT_WF_MAX_SLOTS, VRT_WF_ANY_CAP, VRT_BUILDER, VRT_COLLAPSE_PARITY,
-// VRT_NO_BIG, VRT_PACKET) are read once, when the context is created; vrt_set_option changes
+// VRT_NO_BIG, VRT_PACKET, VRT_BLOCK_COMPACT) are read once, when the context is created; vrt_set_option changes
 // them afterwards.  Nothing on the per-frame path reads the environment.
 struct VrtOptions {
     int xcd_remap = 0;          // 1: each XCD renders one contiguous band of tiles (measured slower)
@@ -23,6 +23,7 @@ struct VrtOptions {
     int collapse_parity = 0;    // 1: collapse every second level instead of by surface area
     int no_big = 0;             // 1: scene-sized primitives stay in the tree
     int packet = -1;            // tree scenes: wave-uniform traversal for the rays of one pixel group; -1 = chosen from spp
+    int block_compact = 0;      // tree scenes, one child per hit: bounces compacted inside four-wave blocks (0: one wave per tile through all bounces)
     int fail_after_build = 0;   // tests: vrt_set_scene reports a failure after uploads and tree build have succeeded
 };
 

@@ -47,7 +47,7 @@ __global__ __launch_bounds__(VRT_MEGA_THREADS, BVH ? VRT_BVH_WAVES : (SIMPLE ? V
     const int bx = bid % blocks_x, by = bid / blocks_x;
     const int lane = threadIdx.x;
     // SPLIT = false is the instantiation for one lane per pixel (sample_shift 0)
-    const int shift = (VRT_USE_SM || !SPLIT) ? 0 : P.sample_shift;
+    const int shift = !SPLIT ? 0 : P.sample_shift;
     const int n_sl = 1 << shift;                       // sample lanes per pixel
     const int pshift = 6 - shift;                      // log2(pixels per wave)
     const int pw_shift = (pshift + 1) >> 1;            // tile width 2^ceil(pshift/2), height 2^floor(pshift/2)
@@ -66,14 +66,7 @@ __global__ __launch_bounds__(VRT_MEGA_THREADS, BVH ? VRT_BVH_WAVES : (SIMPLE ? V
 #if VRT_USE_SM
     __shared__ LdsScene s_scene;
     stage_scene(S, &s_scene);
-    if (inside) {
-        int id;
-        float4 c = trace_pixel_sm<BVH, false, TWOCHILD>(S, cam, P, &s_scene, h, v, -1, id, C, R);
-        size_t idx = (size_t)(P.compact ? r : h) * cam.width + v; // RayTracerUnity.cs:442
-        rgba[idx] = c;
-        if (hit_id) hit_id[idx] = id;
-    }
-#else
+#endif
     f3 raw = mk3(0.f, 0.f, 0.f);
     const float2* off = nullptr;
     if (inside) {
@@ -87,11 +80,20 @@ __global__ __launch_bounds__(VRT_MEGA_THREADS, BVH ? VRT_BVH_WAVES : (SIMPLE ? V
     for (int base = 0; base < P.spp; base += n_sl) {   // wave-uniform trip count
         const int i = base + si;
         f3 c = mk3(0.f, 0.f, 0.f);
+#if VRT_USE_SM
+        {   // the state machine, one sample per lane and round; lanes without a sample ride along
+            const bool act = inside && i < P.spp;
+            int fp;
+            c = trace_samples_sm<BVH, false, TWOCHILD>(S, cam, P, &s_scene, act ? h : 0, act ? v : 0, act ? i : 0, act ? i + 1 : 0, fp, C, R);
+            if (act && i == 0) id = fp;
+        }
+#else
         if (inside && i < P.spp) {
             int fp;
             c = trace_sample_dev<BVH, false, TWOCHILD>(S, cam, P, raw, off, i, fp, C, R);
             if (i == 0) id = fp;
         }
+#endif
         if (shift == 0) {
             sum = sum + c;
         } else {
@@ -116,7 +118,6 @@ __global__ __launch_bounds__(VRT_MEGA_THREADS, BVH ? VRT_BVH_WAVES : (SIMPLE ? V
         }
         if (hit_id) hit_id[idx] = id;
     }
-#endif
     flush_counters(C, ctr, blockIdx.x);
 }
 
@@ -195,11 +196,7 @@ static inline int div_up(int a, int b) { return (a + b - 1) / b; }
 hipError_t vrt_launch_mega(const DevScene& S, const DevCam& cam, const DevParams& P, bool bvh, bool twochild,
                            float4* rgba, int* hit_id, unsigned long long* ctr, hipStream_t stream)
 {
-#if VRT_USE_SM
-    const int shift = 0;
-#else
     const int shift = P.sample_shift;
-#endif
     const int pshift = 6 - shift, pw_shift = (pshift + 1) >> 1;
     int blocks_x = div_up(cam.width, 1 << pw_shift), blocks_y = div_up(P.local_rows, 1 << (pshift - pw_shift));
     int n_blocks = blocks_x * blocks_y;

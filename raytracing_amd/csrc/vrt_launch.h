@@ -5,6 +5,11 @@
 hipError_t vrt_launch_mega(const DevScene& S, const DevCam& cam, const DevParams& P, bool bvh, bool twochild,
                            float4* rgba, int* hit_id, unsigned long long* ctr, hipStream_t stream);
 
+// The megakernel for tree scenes with one child ray per hit, bounces compacted inside blocks of
+// four waves (vrt_blockwf.hip).  Same frame, hit ids and ray counts as vrt_launch_mega.
+hipError_t vrt_launch_mega_blk(const DevScene& S, const DevCam& cam, const DevParams& P, float4* rgba, int* hit_id,
+                               unsigned long long* ctr, hipStream_t stream);
+
 hipError_t vrt_launch_pixels(const DevScene& S, const DevCam& cam, const DevParams& P, bool bvh, bool twochild,
                              const int* pixels, int n_pixels, int sample_sel, vrt_path_seg* segs, int cap,
                              int* seg_counts, float4* rgba_out, int* hit_out, unsigned long long* ctr,

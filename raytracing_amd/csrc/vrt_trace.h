@@ -513,13 +513,19 @@ __device__ __forceinline__ bool trav_stackless(const DevScene& S, Trav& T, bool 
 // node and tests its four child boxes; the hit children are visited nearest first, the others
 // wait on the lane's stack in LDS and are dropped at pop time when a closer hit has been found
 // since.  The result does not depend on the visiting order because candidates are ranked by (t, id).
-__device__ __forceinline__ Hit intersect_bvh4(const DevScene& S, f3 o, f3 d, float maxd, float tlim, int skip, bool any)
+__device__ __forceinline__ bool intersect_bvh4_packet(const DevScene& S, Trav& T, bool live, bool any);
+
+// packet: the calling lanes' rays are expected to stay close to each other and try the
+// wave-uniform traversal first (intersect_bvh4_packet).
+__device__ __forceinline__ Hit intersect_bvh4(const DevScene& S, f3 o, f3 d, float maxd, float tlim, int skip, bool any,
+                                              bool packet = false)
 {
     unsigned long long* my_lds = g_lds_stack + threadIdx.x;
     Trav T;
     trav_begin(T, o, d, maxd, tlim, skip);
     if (is_zero3(d)) return T.best;
     if (trav_big(S, T, any)) return T.best;
+    if (packet && intersect_bvh4_packet(S, T, true, any)) return T.best;
     // every node is entered at most once; the bound only guards against a corrupt tree
     for (int guard = 2 * S.n_prims + 8; guard > 0; --guard) {
         bool pop;
@@ -616,9 +622,10 @@ __device__ __forceinline__ bool intersect_bvh4_packet(const DevScene& S, Trav& T
 
 // Closest hit (ANY = false) or "some hit with t < tlim" (ANY = true) within maxd.
 template <bool BVH, bool ANY, bool CAM = false>
-__device__ __forceinline__ Hit intersect(const DevScene& S, f3 o, f3 d, float maxd, int skip, float tlim = INFINITY)
+__device__ __forceinline__ Hit intersect(const DevScene& S, f3 o, f3 d, float maxd, int skip, float tlim = INFINITY,
+                                         bool packet = false)
 {
-    if (BVH) return intersect_bvh4(S, o, d, maxd, tlim, skip, ANY);
+    if (BVH) return intersect_bvh4(S, o, d, maxd, tlim, skip, ANY, packet);
     return intersect_brute<CAM>(S, o, d, maxd, tlim, skip, ANY);
 }
 
@@ -751,13 +758,14 @@ __device__ __forceinline__ f3 sky_color(f3 direction)
 // queues the query for a later, densely packed pass and one that reads the answers back.
 struct OccInline {
     static constexpr bool counts = true;   // the shading pass that uses this provider counts the rays
+    bool packet = false;                   // the queries of the calling lanes stay close together (hits of camera rays)
     template <bool BVH>
     __device__ __forceinline__ bool occluded(const DevScene& S, int, f3 o, f3 d, float maxd, float tlim, int skip)
     {
 #if VRT_STUDY_NO_ANYHIT   // timing study only: every query answered "free" without a traversal
         return false;
 #else
-        return intersect<BVH, true>(S, o, d, maxd, skip, tlim).prim >= 0;
+        return intersect<BVH, true>(S, o, d, maxd, skip, tlim, packet).prim >= 0;
 #endif
     }
 };
@@ -990,6 +998,7 @@ __device__ __forceinline__ void shade_hit(const DevScene& S, const DevParams& P,
                                           Counters& C, Recorder& R, Bounce& B)
 {
     OccInline occ;
+    occ.packet = BVH && (P.packet == 2 || (P.packet == 1 && depth == 0));
     shade_hit<BVH, RECORD>(S, P, h, o, d, depth, C, R, B, occ);
 }
 
@@ -1033,7 +1042,7 @@ __device__ __forceinline__ f3 trace_path(const DevScene& S, const DevParams& P, 
             h.prim = -1; h.t = INFINITY; h.aux = 0;
             if (!is_zero3(d)) {
                 if (kind == VRT_RAY_REFLECT) VRT_COUNT(C, reflect, VRT_RAY_REFLECT); else VRT_COUNT(C, transmit, VRT_RAY_TRANSMIT);
-                h = intersect<BVH, false>(S, o, d, P.range, skip);
+                h = intersect<BVH, false>(S, o, d, P.range, skip, INFINITY, BVH && P.packet == 2);
                 record_seg<RECORD>(R, o, d, h, kind, depth, P.range);
             }
         }
@@ -1085,7 +1094,7 @@ __device__ __forceinline__ f3 trace_sample_dev(const DevScene& S, const DevCam& 
         // one closest-hit query answers both the any-hit pre-check (RayTracerUnity.cs:582)
         // and the primary TraceRay (:584); they are counted as the two queries they replace
         VRT_COUNT(C, precheck, VRT_RAY_PRECHECK);
-        first = intersect<BVH, false, true>(S, O, d, P.range, -1);
+        first = intersect<BVH, false, true>(S, O, d, P.range, -1, INFINITY, BVH && P.packet);
     }
     first_prim = first.prim;
     if (first.prim >= 0) {
@@ -1193,11 +1202,12 @@ __device__ __forceinline__ f3 light_term(const DevLight& l, f3 wi, float ndotwi,
     return lam * world;
 }
 
-// `lds` = the block's LdsScene filled by stage_scene().
+// Samples i0 .. i1-1 of pixel (ph, pv), their radiances added up in order.  `lds` = the block's
+// LdsScene filled by stage_scene().  Lanes with i0 >= i1 ride along without a sample.
 template <bool BVH, bool RECORD, bool TWOCHILD>
-__device__ __forceinline__ float4 trace_pixel_sm(const DevScene& S, const DevCam& cam, const DevParams& P,
-                                                 const LdsScene* lds, int ph, int pv, int sample_sel,
-                                                 int& hit_id, Counters& C, Recorder& R)
+__device__ __forceinline__ f3 trace_samples_sm(const DevScene& S, const DevCam& cam, const DevParams& P,
+                                               const LdsScene* lds, int ph, int pv, int i0, int i1,
+                                               int& hit_id, Counters& C, Recorder& R)
 {
     const vrt_shading& sh = S.sh;
     const f3 O = mk3(cam.ox, cam.oy, cam.oz);
@@ -1207,7 +1217,6 @@ __device__ __forceinline__ float4 trace_pixel_sm(const DevScene& S, const DevCam
     const float2* off = P.offsets ? P.offsets + (size_t)set * P.spp : nullptr;
     f3 sum = mk3(0.f, 0.f, 0.f);
     hit_id = -1;
-    const int i0 = sample_sel < 0 ? 0 : sample_sel, i1 = sample_sel < 0 ? P.spp : sample_sel + 1;
     int i = i0;
     // path state
     f3 T = mk3(1.f, 1.f, 1.f), L = mk3(0.f, 0.f, 0.f);
@@ -1388,6 +1397,18 @@ __device__ __forceinline__ float4 trace_pixel_sm(const DevScene& S, const DevCam
         if (done) break;
         h = intersect_rt<BVH>(S, qo, qd, qmax, qskip, qlim, qany);
     }
+    return sum;
+}
+
+// RayTracerUnity.cs:565-597 on the state machine: all samples of one pixel (sample_sel < 0) or
+// just that one, averaged and tone-mapped.
+template <bool BVH, bool RECORD, bool TWOCHILD>
+__device__ __forceinline__ float4 trace_pixel_sm(const DevScene& S, const DevCam& cam, const DevParams& P,
+                                                 const LdsScene* lds, int ph, int pv, int sample_sel,
+                                                 int& hit_id, Counters& C, Recorder& R)
+{
+    const int i0 = sample_sel < 0 ? 0 : sample_sel, i1 = sample_sel < 0 ? P.spp : sample_sel + 1;
+    f3 sum = trace_samples_sm<BVH, RECORD, TWOCHILD>(S, cam, P, lds, ph, pv, i0, i1, hit_id, C, R);
     f3 fin = sum / (float)(i1 - i0);
     return process_color(fin);
 }

@@ -178,3 +178,33 @@ def test_linear_rgb_output_then_tonemap_equals_frame(vrt_ctx, mode):
     with pytest.raises(host.VrtError) as e:   # host-buffer frames are always 4 floats per pixel
         vrt_ctx.render(ra.Params(flags=abi.VRT_OUT_LINEAR_RGB, **kw))
     assert e.value.code == abi.VRT_ERR_INVALID
+
+
+@pytest.mark.parametrize("which,spp", [("spheres", 1), ("spheres", 5), ("spheres", 16), ("mesh", 4), ("spheres", 70)])
+def test_block_compaction_is_bitwise_invisible(vrt_ctx, vrt_opts, which, spp):
+    """Tree scenes with one child ray per hit are rendered by a kernel that hands the rays of every
+    bounce out again densely inside blocks of four waves; a sample's radiance is still accumulated
+    term by term in path order, so frames, hit ids and ray counts are those of the kernel in which
+    a lane keeps its sample through all bounces (frame sizes that leave tiles and blocks ragged)."""
+    if which == "spheres":
+        scene, cam, rng = ra.random_spheres_scene(n=900, seed=4), ra.random_spheres_camera(131, 77), 200.0
+    else:
+        scene, cam, rng = ra.tessellated_mesh_scene(quads=40), ra.tessellated_mesh_camera(131, 77), 100.0
+    offs = host.sampler_table(abi.VRT_SAMPLER_RANDOM, spp, 5, 0.02, 0.02, seed=11)
+    vrt_ctx.set_scene(scene)
+    vrt_ctx.set_camera(cam)
+    for flags in (0, abi.VRT_FIX_PRIMARY_SKY | abi.VRT_FIX_AO_BASIS):
+        prm = ra.Params(spp=spp, offsets=offs, seed=5, max_depth=7, rng=rng, flags=flags)
+        vrt_opts("block_compact", 0)
+        a, ah, ast = vrt_ctx.render(prm)
+        a, ah = a.copy(), ah.copy()
+        vrt_opts("block_compact", 1)
+        b, bh, bst = vrt_ctx.render(prm)
+        assert np.array_equal(a, b, equal_nan=True) and np.array_equal(ah, bh)
+        assert list(ast.rays) == list(bst.rays)
+    # strips, packed rows
+    rows = [h for h in range(77) if (h // 8) % 3 == 2]
+    out = np.zeros((len(rows), 131, 4), np.float32)
+    vrt_ctx.render(ra.Params(spp=spp, offsets=offs, seed=5, max_depth=7, rng=rng, flags=flags, tile_index=2, tile_count=3,
+                             tile_rows=8, compact_rows=True), rgba=out, hit=np.zeros((len(rows), 131), np.int32))
+    assert np.array_equal(out, b[rows], equal_nan=True)

@@ -8,9 +8,9 @@ tmp=/tmp/vrt_variant_$name
 mkdir -p $tmp
 flags="${VRT_OPT:--O3} -std=c++17 -fPIC -ffp-contract=off -fno-fast-math --offload-arch=gfx950 -Wno-unused-value $*"
 pids=()
-for f in vrt_api vrt_kernels vrt_bvh vrt_wavefront; do
+for f in vrt_api vrt_kernels vrt_bvh vrt_wavefront vrt_blockwf vrt_multi; do
   /opt/rocm/bin/hipcc $flags -c $src/$f.hip -o $tmp/$f.o & pids+=($!)
 done
 /opt/rocm/bin/hipcc -O2 -std=c++17 -fPIC -ffp-contract=off -c $src/vrt_sampler.cpp -o $tmp/vrt_sampler.o & pids+=($!)
 for p in "${pids[@]}"; do wait $p || exit 1; done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o $root/raytracing_amd/libvrt_$name.so $tmp/*.o && echo built libvrt_$name.so
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o $root/raytracing_amd/libvrt_$name.so $tmp/*.o -ldl -lpthread && echo built libvrt_$name.so
