@@ -275,10 +275,14 @@ int vrt_create_multi(int n_gpus, const int* devices, vrt_ctx** out);
  * the reference. */
 int vrt_set_option(vrt_ctx* ctx, const char* name, long long value);
 
-/* Page-locks a host buffer the caller will hand to vrt_render / vrt_render_begin over and over
- * (the pinned Color[] PixelColorData, Info/TextureInformation.cs:36,58-63), so that the frame
- * read-back runs at PCIe speed instead of through the runtime's staging copies.  The buffer must
- * stay allocated until vrt_host_unregister or vrt_destroy. */
+/* Page-locked host memory for the frame the caller reads back over and over (the Color[]
+ * PixelColorData of Info/TextureInformation.cs:36,58-63, which a Unity host wraps in a NativeArray):
+ * vrt_render / vrt_render_begin copy into such a buffer at PCIe speed instead of through the
+ * runtime's staging copies of pageable memory.  Freed by vrt_host_free or vrt_destroy.
+ * vrt_host_register page-locks a buffer the caller allocated itself; the operating system may
+ * refuse (VRT_ERR_HIP), in which case the buffer still works, only slower. */
+int vrt_host_alloc(vrt_ctx* ctx, uint64_t bytes, void** out);
+int vrt_host_free(vrt_ctx* ctx, void* buffer);
 int vrt_host_register(vrt_ctx* ctx, void* buffer, uint64_t bytes);
 int vrt_host_unregister(vrt_ctx* ctx, void* buffer);
 

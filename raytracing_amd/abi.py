@@ -122,5 +122,5 @@ EXPORTS = (
     "vrt_render_begin", "vrt_render_poll", "vrt_render_end", "vrt_render_device", "vrt_render_device_noalloc",
     "vrt_fetch_stats", "vrt_tonemap_device", "vrt_trace_pixel", "vrt_trace_ray", "vrt_sampler_table",
     "vrt_pixel_set", "vrt_abi_version", "vrt_create_multi", "vrt_set_option", "vrt_host_register",
-    "vrt_host_unregister", "vrt_render_begin_parts", "vrt_render_poll_parts",
+    "vrt_host_unregister", "vrt_host_alloc", "vrt_host_free", "vrt_render_begin_parts", "vrt_render_poll_parts",
 )

@@ -82,6 +82,7 @@ static void options_from_env(VrtOptions& o)
     o.no_big = (int)geti("VRT_NO_BIG", 0);
     o.packet = (int)geti("VRT_PACKET", -1);
     o.block_compact = (int)geti("VRT_BLOCK_COMPACT", 0);
+    o.quad_max = (int)geti("VRT_QUAD_MAX", -1);
 }
 
 extern "C" int vrt_set_option(vrt_ctx* c, const char* name, long long value)
@@ -96,10 +97,12 @@ extern "C" int vrt_set_option(vrt_ctx* c, const char* name, long long value)
     else if (n == "wf_refill") o.wf_refill = value != 0;
     else if (n == "wf_max_slots") o.wf_max_slots = value > 0 ? value : 0;
     else if (n == "wf_any_cap") o.wf_any_cap = value;
+    else if (n == "wf_queue_cap") o.wf_queue_cap = value > 0 ? value : 0;
     else if (n == "builder") o.builder_lbvh = value != 0;
     else if (n == "collapse_parity") o.collapse_parity = value != 0;
     else if (n == "no_big") o.no_big = value != 0;
     else if (n == "block_compact") o.block_compact = value != 0;
+    else if (n == "quad_max") { if (value < -1 || value > 64) return fail(c, VRT_ERR_INVALID, "quad_max: -1..64"); o.quad_max = (int)value; }
     else if (n == "fail_after_build") o.fail_after_build = value != 0;
     else if (n == "packet") { if (value < -1 || value > 2) return fail(c, VRT_ERR_INVALID, "packet: -1, 0, 1 or 2"); o.packet = (int)value; }
     else return fail(c, VRT_ERR_INVALID, "unknown option " + n);
@@ -124,6 +127,14 @@ static void free_wf(vrt_ctx* c)
     memset(&c->wf, 0, sizeof c->wf);
 }
 
+// The runtime page-locks whole pages: the range registered is the caller's buffer widened to page
+// boundaries (what else lies in its first and last page is pinned with it, which is harmless).
+static void page_range(void* p, size_t bytes, void** base, size_t* len)
+{
+    const uintptr_t page = 4096, a = (uintptr_t)p & ~(page - 1), b = ((uintptr_t)p + bytes + page - 1) & ~(page - 1);
+    *base = (void*)a; *len = (size_t)(b - a);
+}
+
 // Releases everything a context owns; every handle may be null (a half-built context).
 static void teardown(vrt_ctx* c)
 {
@@ -136,8 +147,10 @@ static void teardown(vrt_ctx* c)
     hipFree(c->d_rec_pixels); hipFree(c->d_segs); hipFree(c->d_seg_counts);
     hipFree(c->d_px_rgba); hipFree(c->d_px_hit);
     if (c->static_stage) hipHostFree(c->static_stage);
-    for (auto& r : c->registered) hipHostUnregister(r.first);
+    for (auto& r : c->registered) { void* base; size_t len; page_range(r.first, r.second, &base, &len); hipHostUnregister(base); }
     c->registered.clear();
+    for (void* p : c->host_allocs) hipHostFree(p);
+    c->host_allocs.clear();
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
     if (c->ev_done) hipEventDestroy(c->ev_done);
@@ -203,12 +216,41 @@ extern "C" int vrt_destroy(vrt_ctx* c)
     return VRT_OK;
 }
 
+extern "C" int vrt_host_alloc(vrt_ctx* c, uint64_t bytes, void** out)
+{
+    if (!c || !out || !bytes) return fail(c, VRT_ERR_INVALID, "null argument");
+    *out = nullptr;
+    HIPCHK(c, hipSetDevice(c->device));
+    void* p = nullptr;
+    HIPCHK(c, hipHostMalloc(&p, (size_t)bytes, hipHostMallocDefault));
+    c->host_allocs.push_back(p);
+    *out = p;
+    return VRT_OK;
+}
+
+extern "C" int vrt_host_free(vrt_ctx* c, void* p)
+{
+    if (!c || !p) return fail(c, VRT_ERR_INVALID, "null argument");
+    if (c->pending) return fail(c, VRT_ERR_STATE, "a frame started with vrt_render_begin is still in flight");
+    HIPCHK(c, hipSetDevice(c->device));
+    for (size_t i = 0; i < c->host_allocs.size(); ++i)
+        if (c->host_allocs[i] == p) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            HIPCHK(c, hipHostFree(p));
+            c->host_allocs.erase(c->host_allocs.begin() + i);
+            return VRT_OK;
+        }
+    return fail(c, VRT_ERR_INVALID, "buffer was not allocated with vrt_host_alloc on this context");
+}
+
 extern "C" int vrt_host_register(vrt_ctx* c, void* p, uint64_t bytes)
 {
     if (!c || !p || !bytes) return fail(c, VRT_ERR_INVALID, "null argument");
     HIPCHK(c, hipSetDevice(c->device));
     for (auto& r : c->registered) if (r.first == p) return fail(c, VRT_ERR_STATE, "buffer is already registered");
-    HIPCHK(c, hipHostRegister(p, (size_t)bytes, hipHostRegisterDefault));
+    void* base; size_t len;
+    page_range(p, (size_t)bytes, &base, &len);
+    HIPCHK(c, hipHostRegister(base, len, hipHostRegisterDefault));
     c->registered.push_back({p, (size_t)bytes});
     return VRT_OK;
 }
@@ -220,8 +262,10 @@ extern "C" int vrt_host_unregister(vrt_ctx* c, void* p)
     HIPCHK(c, hipSetDevice(c->device));
     for (size_t i = 0; i < c->registered.size(); ++i)
         if (c->registered[i].first == p) {
+            void* base; size_t len;
+            page_range(p, c->registered[i].second, &base, &len);
             HIPCHK(c, hipStreamSynchronize(c->stream));
-            HIPCHK(c, hipHostUnregister(p));
+            HIPCHK(c, hipHostUnregister(base));
             c->registered.erase(c->registered.begin() + i);
             return VRT_OK;
         }
@@ -623,8 +667,10 @@ static int check_params(vrt_ctx* c, const vrt_params* p, DevParams* out)
     }
     if (c->opt.sample_shift >= 0) P.sample_shift = c->opt.sample_shift;
     // Wave-uniform traversal of the tree for the camera rays of a wave and the occlusion rays of
-    // their hits: pays when the lanes of a wave belong to few pixels (>= 16 lanes per pixel).
-    P.packet = c->opt.packet >= 0 ? c->opt.packet : (P.sample_shift >= 4 ? 1 : 0);
+    // their hits: pays when the lanes of a wave belong to few pixels (measured +2.6 % at 16 lanes per
+    // pixel on the 10k-sphere frame, +6 % at 4 lanes per pixel on the 1M-triangle frame).
+    P.packet = c->opt.packet >= 0 ? c->opt.packet : (P.sample_shift >= 2 ? 1 : 0);
+    P.quad_max = c->opt.quad_max >= 0 ? c->opt.quad_max : 16;
     P.offsets = nullptr;
     return VRT_OK;
 }
@@ -665,7 +711,7 @@ static size_t wf_slack(size_t live)
 static int ensure_wf(vrt_ctx* c, size_t slots, bool two, hipStream_t stream)
 {
     const bool defer = c->opt.wf_defer != 0;
-    const bool short_any = c->opt.wf_any_cap >= 0;
+    const bool short_any = c->opt.wf_any_cap >= 0 || c->opt.wf_queue_cap > 0;
     if (c->wf.slots >= slots && (c->wf_two || !two) && (c->wf.hits != nullptr) == defer && !c->wf_short && !short_any) return VRT_OK;
     HIPCHK(c, hipDeviceSynchronize());   // a frame in flight may still use the old workspace
     free_wf(c);
@@ -683,6 +729,9 @@ static int ensure_wf(vrt_ctx* c, size_t slots, bool two, hipStream_t stream)
         HIPCHK(c, hipMemsetAsync(q.pix, 0xff, cap * sizeof(int), stream));   // "unwritten" marks; consumers put them back
     }
     c->wf.cap = cap;
+    if (c->opt.wf_queue_cap > 0 && (size_t)c->opt.wf_queue_cap < cap) {   // tests: ray queues that overflow
+        c->wf.cap = (size_t)c->opt.wf_queue_cap; c->wf_short = true;
+    }
     HIPCHK(c, hipMalloc(&c->wf.lacc, slots * sizeof(float4)));
     HIPCHK(c, hipMalloc(&c->wf.counts, (VRT_MAX_DEPTH + 3) * sizeof(int)));
     if (defer) {
@@ -697,7 +746,7 @@ static int ensure_wf(vrt_ctx* c, size_t slots, bool two, hipStream_t stream)
         a.skip = (int*)(b + 8 * cap); a.target = (int*)(b + 9 * cap); a.bit = (int*)(b + 10 * cap);
         HIPCHK(c, hipMemsetAsync(a.target, 0xff, cap * sizeof(int), stream));
         c->wf.any_cap = cap;
-        if (short_any && (size_t)c->opt.wf_any_cap < cap) {   // tests: a short queue forces the in-place path
+        if (c->opt.wf_any_cap >= 0 && (size_t)c->opt.wf_any_cap < cap) {   // tests: a short queue forces the in-place path
             c->wf.any_cap = (size_t)c->opt.wf_any_cap; c->wf_short = true;
         }
         HIPCHK(c, hipMalloc(&c->wf.any_counts, 3 * (VRT_MAX_DEPTH + 2) * sizeof(int)));

@@ -18,11 +18,13 @@ struct VrtOptions {
     int wf_defer = 1;           // wavefront: occlusion queries of the bounces in a queue of their own
     int wf_refill = 1;          // wavefront: queues traced with lanes refilled as they finish
     long long wf_max_slots = 0; // wavefront: sample slots per band (0 = library default)
+    long long wf_queue_cap = 0; // wavefront, tests: ray queues cut to this many entries (0 = as allocated)
     long long wf_any_cap = -1;  // wavefront: capacity of the occlusion-query queue (-1 = full)
     int builder_lbvh = 0;       // 1: Karras' radix tree instead of PLOC under the 4-wide collapse
     int collapse_parity = 0;    // 1: collapse every second level instead of by surface area
     int no_big = 0;             // 1: scene-sized primitives stay in the tree
     int packet = -1;            // tree scenes: wave-uniform traversal for the rays of one pixel group; -1 = chosen from spp
+    int quad_max = -1;          // tree scenes: waves with at most this many queries trace them four lanes per ray; -1 = library default
     int block_compact = 0;      // tree scenes, one child per hit: bounces compacted inside four-wave blocks (0: one wave per tile through all bounces)
     int fail_after_build = 0;   // tests: vrt_set_scene reports a failure after uploads and tree build have succeeded
 };
@@ -86,6 +88,7 @@ struct vrt_ctx {
     float4* d_px_rgba = nullptr; int* d_px_hit = nullptr;
     // host buffers the caller asked us to page-lock (vrt_host_register)
     std::vector<std::pair<void*, size_t>> registered;
+    std::vector<void*> host_allocs;            // page-locked buffers handed out by vrt_host_alloc
     // wavefront workspace
     WfWorkspace wf; bool wf_two = false; bool wf_short = false;
     // the device's copy of the library's static scratch array (vrt_render_device_noalloc) and the
@@ -105,8 +108,10 @@ int vrt_fail(vrt_ctx* c, int code, const std::string& msg);
 #define HIPCHK(c, expr)                                                                         \
     do {                                                                                        \
         hipError_t e_ = (expr);                                                                 \
-        if (e_ != hipSuccess)                                                                   \
+        if (e_ != hipSuccess) {                                                                 \
+            (void)hipGetLastError(); /* reported here: must not show up at the next launch */   \
             return vrt_fail(c, VRT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+        }                                                                                       \
     } while (0)
 
 // The single-GPU bodies of the entry points, on this context's own GPU whether or not it is the

@@ -86,6 +86,7 @@ struct DevParams {
     int xcd_remap;  // renumber blocks so that each XCD works on one contiguous band of tiles
     int sample_shift; // megakernel: log2 of the lanes that share one pixel's samples (0..6)
     int packet;       // tree scenes: rays a wave casts together take the wave-uniform traversal first
+    int quad_max;     // tree scenes: a wave with at most this many queries traces them four lanes per ray (0 = never)
 };
 
 // Per-call ray counters: 256 slots x 8 words to spread atomic traffic, summed by the host.

@@ -63,37 +63,35 @@ __global__ __launch_bounds__(VRT_MEGA_THREADS, BVH ? VRT_BVH_WAVES : (SIMPLE ? V
 #endif
     Recorder R; R.segs = nullptr; R.cap = 0; R.n = 0; R.sample = 0;
     const bool inside = v < cam.width && r < P.local_rows && h < cam.height;
-#if VRT_USE_SM
+    // see VRT_USE_SM in vrt_trace.h
+    constexpr bool USE_SM = VRT_USE_SM == 1 || (VRT_USE_SM == 2 && BVH);
     __shared__ LdsScene s_scene;
-    stage_scene(S, &s_scene);
-#endif
-    f3 raw = mk3(0.f, 0.f, 0.f);
-    const float2* off = nullptr;
-    if (inside) {
-        raw = camera_raw_dir(cam, h, v);
-        unsigned pixel = (unsigned)(h * cam.width + v);
-        unsigned set = pixel_set_dev(P.seed, pixel, (unsigned)P.n_sets);
-        off = P.offsets ? P.offsets + (size_t)set * P.spp : nullptr;
-    }
+    if constexpr (USE_SM) stage_scene(S, &s_scene);
     f3 sum = mk3(0.f, 0.f, 0.f);
     int id = -1;
     for (int base = 0; base < P.spp; base += n_sl) {   // wave-uniform trip count
         const int i = base + si;
         f3 c = mk3(0.f, 0.f, 0.f);
-#if VRT_USE_SM
-        {   // the state machine, one sample per lane and round; lanes without a sample ride along
+        // per round, not hoisted: these would otherwise stay in registers through every traversal
+        f3 raw = mk3(0.f, 0.f, 0.f);
+        const float2* off = nullptr;
+        if (inside && !USE_SM) {
+            raw = camera_raw_dir(cam, h, v);
+            unsigned pixel = (unsigned)(h * cam.width + v);
+            unsigned set = pixel_set_dev(P.seed, pixel, (unsigned)P.n_sets);
+            off = P.offsets ? P.offsets + (size_t)set * P.spp : nullptr;
+        }
+        if constexpr (USE_SM) {
+            // one sample per lane and round; lanes without a sample ride along
             const bool act = inside && i < P.spp;
             int fp;
             c = trace_samples_sm<BVH, false, TWOCHILD>(S, cam, P, &s_scene, act ? h : 0, act ? v : 0, act ? i : 0, act ? i + 1 : 0, fp, C, R);
             if (act && i == 0) id = fp;
-        }
-#else
-        if (inside && i < P.spp) {
+        } else if (inside && i < P.spp) {
             int fp;
             c = trace_sample_dev<BVH, false, TWOCHILD>(S, cam, P, raw, off, i, fp, C, R);
             if (i == 0) id = fp;
         }
-#endif
         if (shift == 0) {
             sum = sum + c;
         } else {
@@ -142,15 +140,20 @@ __global__ __launch_bounds__(64) void k_pixels(DevScene S, DevCam cam, DevParams
 #endif
     __shared__ LdsScene s_scene;
     stage_scene(S, &s_scene);
-    if (i < n_pixels) {
-        int pix = pixels[i];
-        int h = pix / cam.width, v = pix % cam.width;
-        Recorder R; R.segs = segs + (size_t)i * cap; R.cap = cap; R.n = 0; R.sample = 0;
+    {   // every lane calls (the traversal re-cuts the wave); lanes beyond the list have no sample
+        const bool act = i < n_pixels;
+        const int pix = act ? pixels[i] : 0;
+        const int h = pix / cam.width, v = pix % cam.width;
+        Recorder R; R.segs = act ? segs + (size_t)i * cap : nullptr; R.cap = act ? cap : 0; R.n = 0; R.sample = 0;
         int id;
-        float4 c = trace_pixel_sm<BVH, true, TWOCHILD>(S, cam, P, &s_scene, h, v, sample_sel, id, C, R);
-        seg_counts[i] = R.n;
-        if (rgba_out) rgba_out[i] = c;
-        if (hit_out) hit_out[i] = id;
+        const int i0 = !act ? 0 : (sample_sel < 0 ? 0 : sample_sel), i1 = !act ? 0 : (sample_sel < 0 ? P.spp : sample_sel + 1);
+        f3 sum = trace_samples_sm<BVH, true, TWOCHILD>(S, cam, P, &s_scene, h, v, i0, i1, id, C, R);
+        if (act) {
+            float4 c = process_color(sum / (float)(i1 - i0));
+            seg_counts[i] = R.n;
+            if (rgba_out) rgba_out[i] = c;
+            if (hit_out) hit_out[i] = id;
+        }
     }
     if (ctr) flush_counters(C, ctr, blockIdx.x);
 }

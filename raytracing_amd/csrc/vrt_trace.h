@@ -6,9 +6,14 @@
 #pragma once
 #include "vrt_device.h"
 
-// VRT_USE_SM=1 builds the megakernel on the single-loop state machine (trace_pixel_sm) instead
-// of the straight-line tracer (trace_pixel_dev).  Measured on MI355X: 6 % faster on the 10k-sphere
-// BVH scene, 19 % slower on the 1M-triangle one, 55 % slower on the brute-force teaching scene.
+// VRT_USE_SM selects the tracer of the frame kernel: 0 the straight-line tracer (trace_sample_dev),
+// 1 the single-loop state machine (trace_samples_sm), 2 the state machine for tree scenes only.
+// Measured on MI355X with one sample per lane and round in both: the state machine, whose one
+// traversal site lets sparse waves trace four lanes per ray, runs 62 % of the lanes per vector
+// instruction against 51 % on the 10k-sphere frame but executes 8 % more instructions: 43.7 ms
+// against 41.9 ms (4.14 against 3.64 ms on the 1M-triangle frame), and it is 55 % slower on the
+// brute-force teaching scene.  The frame kernel therefore stays on the straight-line tracer; the
+// recorded-pixel kernel runs the state machine.
 #ifndef VRT_USE_SM
 #define VRT_USE_SM 0
 #endif
@@ -328,10 +333,11 @@ __device__ __forceinline__ void order2(float& ta, int& ca, float& tb, int& cb)
 #ifndef VRT_COUNT_NODES
 #define VRT_COUNT_NODES 0
 #endif
-__device__ __forceinline__ void count_lanes(const DevScene& S, int k)
+__device__ __forceinline__ void count_lanes(const DevScene& S, int k, bool mine = true)
 {
 #if VRT_COUNT_NODES
-    unsigned long long m = __ballot(1);
+    unsigned long long m = __ballot(mine);
+    if (!m) return;
     if ((int)(threadIdx.x & 63) == __ffsll((long long)m) - 1)
         atomicAdd(&S.dbg[(blockIdx.x % VRT_CTR_SLOTS) * VRT_CTR_STRIDE + k], (unsigned long long)__popcll(m));
 #endif
@@ -429,10 +435,10 @@ __device__ __forceinline__ bool trav_inner(const DevScene& S, Trav& T, unsigned 
 }
 
 // Leaf step: tests primitive ~T.node.  Returns true when an any-hit query has its answer.
-__device__ __forceinline__ bool trav_leaf(const DevScene& S, Trav& T, bool any)
+__device__ __forceinline__ bool trav_leaf(const DevScene& S, Trav& T, bool any, bool counted = true)
 {
     const int id = ~T.node;
-    count_lanes(S, 7);
+    count_lanes(S, 7, counted);
     if (id != T.skip) test_prim(S, id, T.o, T.d, T.maxd, T.best);
     if (any && T.best.prim >= 0) {
         if (T.best.t < T.tlim) return true;
@@ -455,11 +461,11 @@ __device__ __forceinline__ bool trav_pop(Trav& T, const unsigned long long* my_l
 
 // Primitives kept out of the tree (DevScene.big), tested ahead of the traversal.  Returns true
 // when an any-hit query has its answer.
-__device__ __forceinline__ bool trav_big(const DevScene& S, Trav& T, bool any)
+__device__ __forceinline__ bool trav_big(const DevScene& S, Trav& T, bool any, bool counted = true)
 {
     for (int k = 0; k < S.n_big; ++k) {
         const int id = S.big[k];
-        count_lanes(S, 7);
+        count_lanes(S, 7, counted);
         if (id != T.skip) test_prim(S, id, T.o, T.d, T.maxd, T.best);
         if (any && T.best.prim >= 0) {
             if (T.best.t < T.tlim) return true;
@@ -618,6 +624,151 @@ __device__ __forceinline__ bool intersect_bvh4_packet(const DevScene& S, Trav& T
     }
     T.best = best;
     return true;
+}
+
+
+// ------------------------------------------------------------------ four lanes per ray
+//
+// Traversal for a wave in which few lanes hold a query (the later bounces: on the 10k-sphere frame
+// 11 % of the lanes are still on a path after two hits, 5 % after three).  A per-lane step costs
+// the wave the same ~120 vector instructions whether 4 or 64 lanes take it, so here the wave is
+// re-cut: up to 16 queries per pass, each given to a quad of four neighbouring lanes, and lane c
+// of a quad tests child c of the quad's node (one box instead of four per lane, 7 dwords instead
+// of 7 x 16 bytes loaded).  The four entry distances are ranked with quad permutes (DPP), the
+// nearest hit child is entered, the others go to the quad's stack, which is the four lanes'
+// stack columns taken together (4 x VRT_TRAV_STACK entries).  Leaves are tested by the four
+// lanes alike, so the quad's state stays replicated without broadcasts.  Box test, primitive
+// tests and the ranking of candidates by (t, id) are those of the per-lane traversal, hence so
+// are the hits.  All 64 lanes of the wave must call; want = this lane holds a query.
+#ifndef VRT_QUAD_MAX
+#define VRT_QUAD_MAX 16
+#endif
+__shared__ int g_lds_quad[VRT_STACK_LANES];   // per wave: 16 x (t bits, primitive, face, source lane)
+
+#define VRT_DPP_ROT1 0x39   // quad_perm [1,2,3,0]
+#define VRT_DPP_ROT2 0x4E   // quad_perm [2,3,0,1]
+#define VRT_DPP_ROT3 0x93   // quad_perm [3,0,1,2]
+__device__ __forceinline__ unsigned quad_rot(unsigned v, int which)
+{
+    if (which == 1) return (unsigned)__builtin_amdgcn_mov_dpp((int)v, VRT_DPP_ROT1, 0xF, 0xF, true);
+    if (which == 2) return (unsigned)__builtin_amdgcn_mov_dpp((int)v, VRT_DPP_ROT2, 0xF, 0xF, true);
+    return (unsigned)__builtin_amdgcn_mov_dpp((int)v, VRT_DPP_ROT3, 0xF, 0xF, true);
+}
+
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// Entry e of the stack of the quad whose first lane is column qcol of the block.
+__device__ __forceinline__ unsigned long long* quad_slot(int qcol, int e)
+{
+    return g_lds_stack + (e >> 2) * VRT_STACK_LANES + qcol + (e & 3);
+}
+
+// Inner-node step of a quad; c = lane & 3.  Returns true when no child was hit (the quad pops).
+__device__ __forceinline__ bool quad_inner(const DevScene& S, Trav& T, int c, int qcol)
+{
+    count_lanes(S, 6, c == 0);
+    const float* nf = (const float*)S.bvh4 + 32 * (size_t)T.node + c;
+    const float lx = nf[0], ly = nf[4], lz = nf[8], hx = nf[12], hy = nf[16], hz = nf[20];
+    const int code = __float_as_int(nf[24]);
+    const float lim = trav_limit(T);
+    // slab_test() on this lane's child
+    const float ax = (lx - T.o.x) * T.inv.x, bx = (hx - T.o.x) * T.inv.x;
+    const float ay = (ly - T.o.y) * T.inv.y, by = (hy - T.o.y) * T.inv.y;
+    const float az = (lz - T.o.z) * T.inv.z, bz = (hz - T.o.z) * T.inv.z;
+    const float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.f));
+    const float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), lim));
+    const bool hit = t0 <= t1 * 1.0000004f;
+    // order key: entry distance (non-negative, so its bits order like the float) with the child
+    // slot in the two lowest bits, which makes the keys of a quad distinct
+    const unsigned key = hit ? ((__float_as_uint(t0) & ~3u) | (unsigned)c) : 0xffffffffu;
+    const unsigned k1 = quad_rot(key, 1), k2 = quad_rot(key, 2), k3 = quad_rot(key, 3);
+    const int n_hit = (int)(key != 0xffffffffu) + (int)(k1 != 0xffffffffu) + (int)(k2 != 0xffffffffu) + (int)(k3 != 0xffffffffu);
+    if (n_hit == 0) return true;
+    const int rank = (int)(k1 < key) + (int)(k2 < key) + (int)(k3 < key);
+    // the nearest child's code, or-ed together over the quad
+    const unsigned mine = (hit && rank == 0) ? (unsigned)code : 0u;
+    const unsigned next = mine | quad_rot(mine, 1) | quad_rot(mine, 2) | quad_rot(mine, 3);
+    // the other hit children wait on the quad's stack, the nearer the higher
+    const int n_push = n_hit - 1;
+    if (hit && rank >= 1) {
+        const int e = T.sp + (n_push - rank);
+        if (e < 4 * VRT_TRAV_STACK) *quad_slot(qcol, e) = ((unsigned long long)__float_as_uint(t0) << 32) | (unsigned)code;
+    }
+    T.sp += n_push;
+    if (T.sp > 4 * VRT_TRAV_STACK) { T.sp = 4 * VRT_TRAV_STACK; T.ovf = true; }   // finished by trav_stackless()
+    T.node = (int)next;
+    return false;
+}
+
+__device__ __forceinline__ bool quad_pop(Trav& T, int qcol)
+{
+    const float lim = trav_limit(T);
+    while (T.sp > 0) {
+        --T.sp;
+        const unsigned long long e = *quad_slot(qcol, T.sp);
+        if (!(__uint_as_float((unsigned)(e >> 32)) > lim)) { T.node = (int)(unsigned)e; return true; }
+    }
+    return false;
+}
+
+__device__ __forceinline__ void intersect_bvh4_quads(const DevScene& S, bool want, f3 o, f3 d, float maxd, float tlim,
+                                                     int skip, bool any, Hit& out)
+{
+    const int lane = threadIdx.x & 63;
+    const unsigned long long m = __ballot(want);
+    const int n = __popcll(m);
+    const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+    int* qs = g_lds_quad + (threadIdx.x & ~63);
+    const int q = lane >> 2, c = lane & 3, qcol = threadIdx.x & ~3;
+    for (int p0 = 0; p0 < n; p0 += 16) {   // wave-uniform
+        const bool mine = want && rank >= p0 && rank < p0 + 16;
+        if (mine) qs[(rank - p0) * 4 + 3] = lane;
+        wave_lds_fence();
+        const bool has = p0 + q < n;
+        const int src = has ? qs[q * 4 + 3] : lane;
+        Trav T;
+        {
+            const f3 qo = mk3(__shfl(o.x, src, 64), __shfl(o.y, src, 64), __shfl(o.z, src, 64));
+            const f3 qd = mk3(__shfl(d.x, src, 64), __shfl(d.y, src, 64), __shfl(d.z, src, 64));
+            trav_begin(T, qo, qd, __shfl(maxd, src, 64), __shfl(tlim, src, 64), __shfl(skip, src, 64));
+        }
+        const bool qany = __shfl((int)any, src, 64) != 0;
+        bool done = !has, found = false;
+        if (!done && trav_big(S, T, qany, c == 0)) { done = true; found = true; }
+        int guard = 2 * S.n_prims + 8;   // only a corrupt tree gets there
+        while (__any(!done)) {
+            if (!done) {
+                bool pop;
+                if (T.node >= 0) pop = quad_inner(S, T, c, qcol);
+                else { if (trav_leaf(S, T, qany, c == 0)) { done = true; found = true; } pop = true; }
+                if (!done && pop && !quad_pop(T, qcol)) done = true;
+                if (--guard <= 0) done = true;
+            }
+        }
+        if (has && !found && T.ovf) trav_stackless(S, T, qany);
+        if (has && c == 0) { qs[q * 4] = __float_as_int(T.best.t); qs[q * 4 + 1] = T.best.prim; qs[q * 4 + 2] = T.best.aux; }
+        wave_lds_fence();
+        if (mine) {
+            const int* r = qs + (rank - p0) * 4;
+            out.t = __int_as_float(r[0]); out.prim = r[1]; out.aux = r[2];
+        }
+        wave_lds_fence();
+    }
+}
+
+// One query per lane of a whole wave (all 64 lanes call; want = this lane has one): four lanes per
+// ray when few lanes ask, else the per-lane traversal, wave-uniform first when the queries are
+// known to stay close together (coherent, wave-uniform).
+__device__ __forceinline__ void intersect_bvh4_wave(const DevScene& S, bool want, f3 o, f3 d, float maxd, float tlim,
+                                                    int skip, bool any, bool coherent, int quad_max, Hit& out)
+{
+    const int n = __popcll(__ballot(want));
+    if (n <= quad_max) intersect_bvh4_quads(S, want, o, d, maxd, tlim, skip, any, out);
+    else if (want) out = intersect_bvh4(S, o, d, maxd, tlim, skip, any, coherent);
 }
 
 // Closest hit (ANY = false) or "some hit with t < tlim" (ANY = true) within maxd.
@@ -1235,7 +1386,7 @@ __device__ __forceinline__ f3 trace_samples_sm(const DevScene& S, const DevCam& 
     int st = ST_SAMPLE;
     bool done = false;
 
-    while (!done) {
+    for (;;) {
         bool query = false;
         while (!query && !done) {
             if (st == ST_SAMPLE) {
@@ -1394,8 +1545,13 @@ __device__ __forceinline__ f3 trace_samples_sm(const DevScene& S, const DevCam& 
                 }
             }
         }
-        if (done) break;
-        h = intersect_rt<BVH>(S, qo, qd, qmax, qskip, qlim, qany);
+        if (!__any(query)) break;   // wave-uniform: every lane has finished its samples
+        if constexpr (BVH) {
+            const bool coherent = P.packet != 0 && __all(!query || depth == 0);
+            intersect_bvh4_wave(S, query, qo, qd, qmax, qlim, qskip, qany, coherent, P.quad_max, h);
+        } else {
+            if (query) h = intersect_rt<BVH>(S, qo, qd, qmax, qskip, qlim, qany);
+        }
     }
     return sum;
 }

@@ -42,6 +42,10 @@ def load_library():
     L.vrt_create_multi.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(vp)]
     L.vrt_set_option.restype = C.c_int
     L.vrt_set_option.argtypes = [vp, C.c_char_p, C.c_longlong]
+    L.vrt_host_alloc.restype = C.c_int
+    L.vrt_host_alloc.argtypes = [vp, C.c_uint64, C.POINTER(vp)]
+    L.vrt_host_free.restype = C.c_int
+    L.vrt_host_free.argtypes = [vp, vp]
     L.vrt_host_register.restype = C.c_int
     L.vrt_host_register.argtypes = [vp, vp, C.c_uint64]
     L.vrt_host_unregister.restype = C.c_int
@@ -148,6 +152,18 @@ class Context:
     def set_option(self, name, value):
         """Study/test knob by name (vrt_set_option); none changes a result."""
         self._chk(self._lib.vrt_set_option(self._h, name.encode(), int(value)))
+
+    def host_alloc(self, shape, dtype=np.float32):
+        """A numpy array over page-locked memory of the library (vrt_host_alloc); frames land in it
+        at PCIe speed.  Valid until host_free(array) or close()."""
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = C.c_void_p()
+        self._chk(self._lib.vrt_host_alloc(self._h, n, C.byref(p)))
+        buf = (C.c_char * n).from_address(p.value)
+        return np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+    def host_free(self, array):
+        self._chk(self._lib.vrt_host_free(self._h, array.ctypes.data))
 
     def host_register(self, array):
         """Page-locks a numpy array that will receive frames (vrt_host_register)."""

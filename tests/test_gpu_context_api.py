@@ -1,0 +1,237 @@
+"""Context-level behaviour of the C ABI on a GPU: the multi-GPU context (vrt_create_multi), frames
+delivered in parts, transactional scene replacement, page-locked caller buffers, the sampler-table
+cache under frames in flight, and error reporting of the wavefront queues."""
+import time
+
+import numpy as np
+import pytest
+
+import raytracing_amd as ra
+from raytracing_amd import abi, host
+
+pytestmark = pytest.mark.gpu
+
+
+def _spheres(w=160, h=93):
+    offs = host.sampler_table(abi.VRT_SAMPLER_JITTERED, 4, 7, 0.01, 0.01, seed=2)
+    return (ra.random_spheres_scene(1200, seed=9), ra.random_spheres_camera(w, h),
+            dict(spp=4, offsets=offs, seed=3, max_depth=5, rng=200.0))
+
+
+@pytest.mark.parametrize("n", [1, 2, 3])
+@pytest.mark.parametrize("which", ["teaching", "spheres"])
+def test_multi_gpu_context_equals_one_gpu(vrt_ctx, oracle_mod, which, n):
+    """vrt_create_multi renders strips on every GPU of the context, gathers them on the first and
+    tone-maps there; the frame, the hit ids and the ray counts are those of the one-GPU context.
+    A one-GPU box stands in for the node by naming GPU 0 several times (the strips then travel by
+    peer-to-peer copies instead of RCCL): strip bookkeeping, ragged last strips, assembly, statistics
+    and path records all run as they do across GPUs."""
+    if which == "teaching":
+        scene, cam, kw = ra.teaching_scene(), ra.teaching_camera(150, 85), dict(spp=1, max_depth=5)
+    else:
+        scene, cam, kw = _spheres()
+    vrt_ctx.set_scene(scene)
+    vrt_ctx.set_camera(cam)
+    want, want_hit, want_st = vrt_ctx.render(ra.Params(**kw))
+    m = host.Context(devices=[0] * n)
+    try:
+        m.set_scene(scene)
+        m.set_camera(cam)
+        for rows in (8, 5):
+            got, got_hit, st = m.render(ra.Params(tile_rows=rows, **kw))
+            assert np.array_equal(got, want, equal_nan=True) and np.array_equal(got_hit, want_hit)
+            assert list(st.rays) == list(want_st.rays) and st.pixels == cam.width * cam.height
+            assert st.gpu_ms > 0
+        # without hit ids, and with path records (traced on the first GPU)
+        got, none, _ = m.render(ra.Params(**kw), want_hit=False)
+        assert none is None and np.array_equal(got, want, equal_nan=True)
+        prm = ra.Params(**kw)
+        px = [3 * cam.width + 7, 40 * cam.width + 90]
+        segs, counts = prm.record(px, 64)
+        m.render(prm)
+        ref = ra.Params(**kw)
+        rsegs, rcounts = ref.record(px, 64)
+        vrt_ctx.render(ref)
+        assert list(counts) == list(rcounts) and min(counts) > 0
+        for k, n_seg in enumerate(counts):   # entries beyond a pixel's count are not written
+            assert bytes(segs)[k * 64 * 40:(k * 64 + n_seg) * 40] == bytes(rsegs)[k * 64 * 40:(k * 64 + n_seg) * 40]
+        # the calls that make no sense across GPUs say so
+        with pytest.raises(host.VrtError) as e:
+            m.render_begin(ra.Params(**kw), got)
+        assert e.value.code == abi.VRT_ERR_INVALID
+        with pytest.raises(host.VrtError):
+            m.render(ra.Params(tile_index=0, tile_count=2, **kw))
+        # per-pixel and per-ray calls run on the first GPU
+        a = m.trace_pixel(ra.Params(**kw), 11, 13)
+        b = vrt_ctx.trace_pixel(ra.Params(**kw), 11, 13)
+        assert np.array_equal(a[0], b[0], equal_nan=True) and a[1] == b[1] and a[3] == b[3]
+    finally:
+        m.close()
+
+
+def test_multi_gpu_scene_replacement_is_all_or_nothing(vrt_ctx):
+    scene, cam, kw = _spheres(96, 64)
+    m = host.Context(devices=[0, 0])
+    try:
+        m.set_scene(scene)
+        m.set_camera(cam)
+        before, _, _ = m.render(ra.Params(**kw))
+        m.set_option("fail_after_build", 1)
+        with pytest.raises(host.VrtError):
+            m.set_scene(ra.random_spheres_scene(500, seed=1))
+        m.set_option("fail_after_build", 0)
+        after, _, _ = m.render(ra.Params(**kw))
+        assert np.array_equal(before, after, equal_nan=True)
+    finally:
+        m.close()
+
+
+def test_failed_scene_upload_keeps_the_old_scene(vrt_ctx, vrt_opts):
+    """A failure after validation (uploads, tree build) must leave the context on its old scene:
+    the new one is assembled beside it and swapped in only on success."""
+    scene, cam, kw = _spheres(96, 64)
+    vrt_ctx.set_scene(scene)
+    vrt_ctx.set_camera(cam)
+    before, bh, bst = vrt_ctx.render(ra.Params(**kw))
+    vrt_opts("fail_after_build", 1)
+    with pytest.raises(host.VrtError) as e:
+        vrt_ctx.set_scene(ra.tessellated_mesh_scene(quads=20))
+    assert e.value.code == abi.VRT_ERR_HIP
+    vrt_opts("fail_after_build", 0)
+    after, ah, ast = vrt_ctx.render(ra.Params(**kw))
+    assert np.array_equal(before, after, equal_nan=True) and np.array_equal(bh, ah)
+    assert list(bst.rays) == list(ast.rays) and ast.bvh_nodes == bst.bvh_nodes
+
+
+@pytest.mark.parametrize("n_parts", [1, 3, 7])
+def test_frame_delivered_in_parts(vrt_ctx, n_parts):
+    """vrt_render_begin_parts delivers the frame strip set by strip set; a part's rows are final
+    once vrt_render_poll_parts counts it, the other rows of the caller's buffer are untouched
+    until their part lands, and the statistics are those of the whole frame."""
+    scene, cam, kw = _spheres(200, 117)
+    vrt_ctx.set_scene(scene)
+    vrt_ctx.set_camera(cam)
+    ref, ref_hit, ref_st = vrt_ctx.render(ra.Params(**kw))
+    rgba = vrt_ctx.host_alloc(ref.shape, np.float32)
+    rgba[:] = -7.0
+    hit = np.full_like(ref_hit, -7)
+    try:
+        vrt_ctx.render_begin_parts(ra.Params(tile_rows=8, **kw), rgba, hit, n_parts)
+        seen, deadline = 0, time.time() + 60
+        while seen < n_parts:
+            done = vrt_ctx.render_poll_parts()
+            assert done >= seen and time.time() < deadline
+            for k in range(seen, done):
+                rows = [h for h in range(cam.height) if (h // 8) % n_parts == k]
+                assert np.array_equal(rgba[rows], ref[rows], equal_nan=True)
+                assert np.array_equal(hit[rows], ref_hit[rows])
+            seen = done
+        assert vrt_ctx.render_poll()
+        st = vrt_ctx.render_end()
+        assert np.array_equal(rgba, ref, equal_nan=True) and np.array_equal(hit, ref_hit)
+        assert list(st.rays) == list(ref_st.rays) and st.pixels == cam.width * cam.height
+        with pytest.raises(host.VrtError) as e:
+            vrt_ctx.render_poll_parts()
+        assert e.value.code == abi.VRT_ERR_STATE
+        with pytest.raises(host.VrtError) as e:
+            vrt_ctx.render_begin_parts(ra.Params(**kw), rgba, hit, 0)
+        assert e.value.code == abi.VRT_ERR_INVALID
+    finally:
+        vrt_ctx.host_free(rgba)
+
+
+def test_strip_calls_copy_only_their_rows(vrt_ctx):
+    """A strip-sharded call into a whole-frame buffer writes the rows it owns and nothing else."""
+    scene, cam, kw = _spheres(120, 70)
+    vrt_ctx.set_scene(scene)
+    vrt_ctx.set_camera(cam)
+    ref, ref_hit, _ = vrt_ctx.render(ra.Params(**kw))
+    rgba = np.full_like(ref, -3.0)
+    hit = np.full_like(ref_hit, -3)
+    vrt_ctx.render(ra.Params(tile_index=1, tile_count=3, tile_rows=8, **kw), rgba=rgba, hit=hit)
+    mine = np.array([(h // 8) % 3 == 1 for h in range(cam.height)])
+    assert np.array_equal(rgba[mine], ref[mine], equal_nan=True) and np.array_equal(hit[mine], ref_hit[mine])
+    assert (rgba[~mine] == -3.0).all() and (hit[~mine] == -3).all()
+
+
+def test_page_locked_host_buffers(vrt_ctx):
+    """Frames land in buffers of vrt_host_alloc like in any other; registering a caller's own buffer
+    is allowed to be refused by the operating system, and then the buffer still works."""
+    scene, cam, kw = _spheres(96, 64)
+    vrt_ctx.set_scene(scene)
+    vrt_ctx.set_camera(cam)
+    ref, ref_hit, _ = vrt_ctx.render(ra.Params(**kw))
+    rgba, hit = vrt_ctx.host_alloc(ref.shape, np.float32), vrt_ctx.host_alloc(ref_hit.shape, np.int32)
+    rgba[:] = 0
+    vrt_ctx.render(ra.Params(**kw), rgba=rgba, hit=hit)
+    assert np.array_equal(rgba, ref, equal_nan=True) and np.array_equal(hit, ref_hit)
+    vrt_ctx.host_free(hit)
+    vrt_ctx.host_free(rgba)
+    with pytest.raises(host.VrtError) as e:
+        vrt_ctx.host_free(ref)
+    assert e.value.code == abi.VRT_ERR_INVALID
+    own = np.zeros_like(ref)
+    try:
+        vrt_ctx.host_register(own)
+        registered = True
+    except host.VrtError as e:
+        assert e.code == abi.VRT_ERR_HIP
+        registered = False
+    vrt_ctx.render(ra.Params(**kw), rgba=own, hit=None, want_hit=False)
+    assert np.array_equal(own, ref, equal_nan=True)
+    if registered:
+        with pytest.raises(host.VrtError) as e:
+            vrt_ctx.host_register(own)
+        assert e.value.code == abi.VRT_ERR_STATE
+        vrt_ctx.host_unregister(own)
+    with pytest.raises(host.VrtError) as e:
+        vrt_ctx.host_unregister(own)
+    assert e.value.code == abi.VRT_ERR_INVALID
+
+
+def test_frames_in_flight_keep_their_sampler_table(vrt_ctx):
+    """Frames queued on a caller stream with different sampler tables (more tables than the cache
+    has slots) must each sample with their own table, whatever is uploaded after them."""
+    import torch
+    scene, cam = ra.teaching_scene(), ra.teaching_camera(320, 180)
+    vrt_ctx.set_scene(scene)
+    vrt_ctx.set_camera(cam)
+    tables = [host.sampler_table(abi.VRT_SAMPLER_RANDOM, 4, 3, 0.02, 0.02, seed=s) for s in range(6)]
+    prms = [ra.Params(spp=4, offsets=t, seed=1, max_depth=5) for t in tables]
+    want = [vrt_ctx.render(p)[0].copy() for p in prms]
+    side = torch.cuda.Stream()
+    outs = [torch.empty((180, 320, 4), device="cuda") for _ in prms]
+    for _ in range(3):
+        for p, o in zip(prms, outs):
+            vrt_ctx.render_device(p, o.data_ptr(), None, side.cuda_stream)
+    torch.cuda.synchronize()
+    for w, o in zip(want, outs):
+        assert np.array_equal(o.cpu().numpy(), w, equal_nan=True)
+
+
+def test_wavefront_overflow_is_reported_without_stats(vrt_ctx, vrt_opts):
+    """A wavefront frame whose ray queues overflowed has dropped paths; every blocking call must
+    say so whether or not the caller asked for statistics (the queues are cut short here)."""
+    import ctypes as C
+    scene, cam = ra.teaching_scene(), ra.teaching_camera(64, 48)
+    vrt_ctx.set_scene(scene)
+    vrt_ctx.set_camera(cam)
+    kw = dict(spp=1, max_depth=6, mode=abi.VRT_MODE_WAVEFRONT)
+    ref, _, ref_st = vrt_ctx.render(ra.Params(**kw))
+    assert ref_st.rays[abi.VRT_RAY_REFLECT] > 400
+    vrt_opts("wf_queue_cap", 300)
+    rgba = np.zeros_like(ref)
+    prm = ra.Params(**kw)
+    with pytest.raises(host.VrtError) as e:
+        vrt_ctx.render(prm)
+    assert e.value.code == abi.VRT_ERR_CAPACITY
+    with pytest.raises(host.VrtError) as e:   # no statistics asked for
+        vrt_ctx._chk(vrt_ctx._lib.vrt_render(vrt_ctx._h, C.byref(prm.c), rgba.ctypes.data, None, None))
+    assert e.value.code == abi.VRT_ERR_CAPACITY
+    vrt_ctx.render_begin(prm, rgba)
+    with pytest.raises(host.VrtError) as e:
+        vrt_ctx._chk(vrt_ctx._lib.vrt_render_end(vrt_ctx._h, None))
+    assert e.value.code == abi.VRT_ERR_CAPACITY
+    vrt_opts("wf_queue_cap", 0)
+    again, _, st = vrt_ctx.render(prm)
+    assert np.array_equal(again, ref, equal_nan=True) and list(st.rays) == list(ref_st.rays)
