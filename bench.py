@@ -93,12 +93,14 @@ def algorithmic_flops(scene, rays, pixels):
     return queries * per_query + shaded * (25 + 30 * len(scene.lights)) + pixels * 12 + shaded * 8
 
 
-def profiled_counters(workload, prefix="r01"):
+def profiled_counters(workload, prefix="r02"):
     """Issue-side view of the dominant kernel from the rocprofv3 summaries committed under
     profiles/ (not measured live): share of the chip's vector-ALU issue slots the kernel used
     (one wave64 instruction occupies a SIMD for 4 cycles; 1024 SIMDs at 2.4 GHz) and the mean
     fraction of the 64 lanes active per vector instruction."""
     import csv
+    if not os.path.exists(os.path.join(ROOT, "profiles", f"{prefix}_{workload}_pmc.csv")):
+        prefix = "r01"
     try:
         pmc = {r["counter"]: float(r["mean_per_dispatch"])
                for r in csv.DictReader(open(os.path.join(ROOT, "profiles", f"{prefix}_{workload}_pmc.csv")))}
@@ -114,9 +116,55 @@ def profiled_counters(workload, prefix="r01"):
         return None
 
 
+def tree_roofline(workload, scene, st, rays, queries, kernel_ms, fb_bytes):
+    """What bounds the frame kernel of a scene traced through the 4-wide tree, from what the kernel
+    itself incurs: per ray it enters `nodes_per_ray` wide nodes (128 B each, seven 16-byte loads per
+    lane, four slab tests) and tests `prims_per_ray` primitives (measured with a -DVRT_COUNT_NODES=1
+    build, kept in profiles/traversal.json).  Those loads hit the vector L1 (98 %), so they are
+    priced against the L1 rate, the measured HBM bytes against the HBM rate, and the arithmetic
+    against the FP32 vector peak: the vector ALUs are the roof that is closest."""
+    trav = None
+    if st.nodes_visited:
+        trav = {"nodes_per_ray": st.nodes_visited / max(queries, 1), "prims_per_ray": st.prims_tested / max(queries, 1),
+                "source": "this run (counting build)"}
+    else:
+        try:
+            trav = dict(json.load(open(os.path.join(ROOT, "profiles", "traversal.json")))[workload])
+            trav["source"] = "profiles/traversal.json"
+        except Exception:
+            pass
+    secs = kernel_ms * 1e-3
+    n_sph, n_box, n_tri = len(scene.spheres), len(scene.boxes), len(scene.indices)
+    n_prims = max(n_sph + n_box + n_tri, 1)
+    prim_bytes = (16 * n_sph + 64 * n_box + 48 * n_tri) / n_prims
+    prim_flops = (17 * n_sph + 30 * n_box + 40 * n_tri) / n_prims
+    shaded = int(rays[abi.VRT_RAY_PRIMARY] + rays[abi.VRT_RAY_REFLECT] + rays[abi.VRT_RAY_TRANSMIT])
+    roof = {"bound": "valu", "unit": "TFLOP/s", "peak": PEAK_FP32_TFLOPS, "traffic": None,
+            "kernel": "k_mega<bvh>" if st.mode_used == abi.VRT_MODE_MEGAKERNEL else "k_wf_*", "kernel_ms": kernel_ms,
+            "framebuffer_bytes_per_launch": fb_bytes}
+    if trav:
+        # a slab test: 6 subtractions, 6 multiplications, 10 min/max, 2 for the comparison = 24 per box
+        flops = queries * (trav["nodes_per_ray"] * 4 * 24 + trav["prims_per_ray"] * prim_flops) \
+            + shaded * (25 + 30 * len(scene.lights) + 8) + st.pixels * 12
+        l1_bytes = queries * (trav["nodes_per_ray"] * 128 + trav["prims_per_ray"] * prim_bytes)
+        ach = flops / secs / 1e12
+        l1_peak = 256 * 64 * 2.4   # GB/s: 256 CUs x 64 B per clock x 2.4 GHz
+        roof.update({"achieved": ach, "frac": ach / PEAK_FP32_TFLOPS, "algorithmic_flops_per_launch": flops,
+                     "traversal": trav,
+                     "l1": {"bytes_per_launch": l1_bytes, "achieved_GBps": l1_bytes / secs / 1e9, "peak_GBps": l1_peak,
+                            "frac": l1_bytes / secs / 1e9 / l1_peak},
+                     "note": "arithmetic of the box and primitive tests the rays of this frame need (bookkeeping "
+                             "excluded) against the FP32 vector peak; node and primitive loads against the vector-L1 "
+                             "rate; measured HBM bytes in `traffic`.  `profiled` holds the issue-slot share and lane "
+                             "activity of the committed counter passes"})
+    else:
+        roof.update({"achieved": None, "frac": None, "note": "profiles/traversal.json missing: no per-ray node counts"})
+    return roof
+
+
 def cpu_baseline(scene, cam, prm):
     """Times the CPU oracle (a restatement of the reference algorithm, not the Unity player) on
-    this host: the whole frame once on one core, then once on all cores the box grants us."""
+    this host: a bounded sub-frame once on one core, then once on every core this job may use."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle
     oracle.build()
@@ -128,14 +176,24 @@ def cpu_baseline(scene, cam, prm):
     t0 = time.perf_counter()
     _, _, rays = oracle.render(scene, scam, prm.c, n_threads=1)
     t1 = time.perf_counter()
-    nthr = min(16, os.cpu_count() or 1)
+    # every core this job may use: the scheduler's affinity mask, capped by OMP_NUM_THREADS when the
+    # box sets it (os.cpu_count() shows the whole machine there)
+    nproc = os.cpu_count() or 1
+    try:
+        allowed = len(os.sched_getaffinity(0))
+    except Exception:
+        allowed = nproc
+    nthr = allowed
+    if os.environ.get("OMP_NUM_THREADS", "").isdigit():
+        nthr = max(1, min(nthr, int(os.environ["OMP_NUM_THREADS"])))
     _, _, rays2 = oracle.render(scene, scam, prm.c, n_threads=nthr)
     t2 = time.perf_counter()
     q = float(sum(int(r) for r in rays[1:]))
     return {"value": q / (t1 - t0) / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port",
             "sample": f"{sw}x{sh} sub-frame of the same camera and scene ({q:.0f} rays), oracle/vrt_oracle.c serial",
             "ms_per_sample_frame": (t1 - t0) * 1e3,
-            "omp_value": q / (t2 - t1) / 1e6, "omp_cores": nthr}
+            "omp_value": q / (t2 - t1) / 1e6, "omp_cores": nthr,
+            "nproc": nproc, "cores_allowed": allowed, "omp_num_threads_env": os.environ.get("OMP_NUM_THREADS")}
 
 
 def scaling_8k(local_rank, world, rank, dev, cdev, rehearsal, frames, tile_rows, mode):
@@ -236,6 +294,8 @@ def main():
     ap.add_argument("--frames-8k", type=int, default=2,
                     help="frames of the 8K x 64 spp strong-scaling measurement reported as `scaling_8k` "
                          "(0 = skip it)")
+    ap.add_argument("--min-time", type=float, default=0.5,
+                    help="the timed region of --steps steps is repeated until this many seconds are timed")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="study option of the library (vrt_set_option), e.g. --opt packet=0")
     args = ap.parse_args()
@@ -364,28 +424,38 @@ def main():
     torch.cuda.synchronize()
     kernel_ms = ev0.elapsed_time(ev1) / max(args.steps, 1)
 
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    drain()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    def timed_region():
+        """EXACTLY args.steps steps between barrier + device synchronisation on both sides."""
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        drain()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        t = torch.tensor([el], dtype=torch.float64, device=cdev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)   # the slowest rank's clock, the same on every rank
+        return float(t[0])
 
-    tot = torch.tensor([elapsed, float(my_queries)], dtype=torch.float64, device=cdev)
+    # The region is repeated until at least --min-time seconds have been timed (a 1080p frame takes
+    # 0.15 ms: a few dozen steps are over before the clocks have settled); a step stays one frame,
+    # and the figure reported is the median region.
+    regions = [timed_region()]
+    n_rep = int(min(max(1, np.ceil(args.min_time / max(regions[0], 1e-9))), 200))
+    for _ in range(n_rep - 1):
+        regions.append(timed_region())
+    elapsed = float(np.median(regions))
+
+    tot = torch.tensor([float(my_queries)], dtype=torch.float64, device=cdev)
     if world > 1:
-        mx = tot.clone()
-        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        sm = tot.clone()
-        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
-        elapsed, queries = float(mx[0]), float(sm[1])
-    else:
-        queries = float(my_queries)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    queries = float(tot[0])
 
     s8k = None
     if args.frames_8k > 0 and args.workload == "c2":
@@ -406,12 +476,7 @@ def main():
                     "note": "FP32 vector-ALU bound (no dense contraction, primitives in scalar registers); "
                             "peak is the MI355X FP32 vector rate"}
         else:
-            by = my_queries * 120 + fb_bytes
-            ach = by / (kernel_ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                    "frac": ach / PEAK_HBM_GBPS, "traffic": None, "kernel_ms": kernel_ms,
-                    "algorithmic_bytes_per_launch": by,
-                    "note": "120 B per ray (ray + hit records) + 20 B per pixel; BVH node traffic not included"}
+            roof = tree_roofline(args.workload, scene, st, rays, my_queries, kernel_ms, fb_bytes)
         prof = profiled_counters(args.workload)
         if prof:
             roof["profiled"] = prof
@@ -421,12 +486,19 @@ def main():
                 roof["traffic"] = json.load(open(tpath)).get(args.workload)
             except Exception:
                 pass
+        if roof.get("traffic"):
+            roof["hbm_measured_GBps"] = roof["traffic"] / (kernel_ms * 1e-3) / 1e9
+            roof["hbm_measured_frac"] = roof["hbm_measured_GBps"] / PEAK_HBM_GBPS
         out = {
             "metric": "Mrays/s (primary+secondary) at 1080p depth 5",
             "value": queries * args.steps / elapsed / 1e6,
             "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step,
+            "timing": {"regions": len(regions), "steps_per_region": args.steps,
+                       "ms_per_step_min": min(regions) * 1e3 / args.steps,
+                       "ms_per_step_median": ms_per_step,
+                       "ms_per_step_max": max(regions) * 1e3 / args.steps},
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -451,17 +523,35 @@ def main():
         if s8k is not None:
             out["scaling_8k"] = s8k
         if world == 1:
-            # the boundary with host buffers (vrt_render): render + PCIe read-back into pageable
-            # memory; reported for reference only, never as `value`
+            # The boundary call itself: vrt_render with the frame delivered to host memory, i.e. the
+            # `ms/frame` a Unity host sees.  Page-locked buffers of the library (vrt_host_alloc, what
+            # the adapter gives PixelColorData) and, for reference, pageable numpy arrays.  Never `value`.
             hp = ra.Params(offsets=offsets, mode=mode, **kw)
+
+            def host_ms(rgba, hit, n):
+                ctx.render(hp, rgba=rgba, hit=hit, want_hit=hit is not None)
+                ts = []
+                for _ in range(n):
+                    t0 = time.perf_counter()
+                    ctx.render(hp, rgba=rgba, hit=hit, want_hit=hit is not None)
+                    ts.append((time.perf_counter() - t0) * 1e3)
+                return float(np.median(ts))
+
+            n_host = int(min(50, max(3, 200.0 / max(kernel_ms, 0.05))))
+            p_rgba, p_hit = ctx.host_alloc((H, W, 4), np.float32), ctx.host_alloc((H, W), np.int32)
+            out["ms_per_frame_host"] = host_ms(p_rgba, p_hit, n_host)
+            out["ms_per_frame_host_no_hit_ids"] = host_ms(p_rgba, None, n_host)
+            ctx.host_free(p_hit)
+            ctx.host_free(p_rgba)
             h_rgba = np.zeros((H, W, 4), np.float32)
             h_hit = np.zeros((H, W), np.int32)
-            ctx.render(hp, rgba=h_rgba, hit=h_hit)
-            t0 = time.perf_counter()
-            for _ in range(3):
-                ctx.render(hp, rgba=h_rgba, hit=h_hit)
-            host_ms = (time.perf_counter() - t0) * 1e3 / 3
-            out["host_buffer_path"] = {"ms_per_frame": host_ms, "Mrays_per_s": queries / host_ms / 1e3}
+            pageable = host_ms(h_rgba, h_hit, min(n_host, 5))
+            out["host_buffer_path"] = {
+                "what": "vrt_render incl. device-to-host copy of the frame (16 B/pixel) and the hit ids (4 B/pixel)",
+                "ms_per_frame_page_locked": out["ms_per_frame_host"],
+                "ms_per_frame_page_locked_no_hit_ids": out["ms_per_frame_host_no_hit_ids"],
+                "ms_per_frame_pageable": pageable,
+                "Mrays_per_s_page_locked": queries / out["ms_per_frame_host"] / 1e3}
         if world == 1 and args.emulate_ranks > 1:
             n = args.emulate_ranks
             per_rank, per_rank_rays = [], []

@@ -4,6 +4,6 @@
 wl=$1; steps=$2; shift 2
 for round in 1 2 3; do
   for o in "$@"; do
-    timeout -k 10 200 python3 bench.py --workload $wl --steps $steps --warmup 2 --no-cpu-baseline --frames-8k 0 $o | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('[$o]', round(d['ms_per_frame_kernel'],4), 'ms', round(d['value'],1), 'Mrays/s')" || exit 1
+    timeout -k 10 200 python3 bench.py --workload $wl --steps $steps --warmup 2 --min-time 0 --no-cpu-baseline --frames-8k 0 $o | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('[$o]', round(d['ms_per_frame_kernel'],4), 'ms', round(d['value'],1), 'Mrays/s')" || exit 1
   done
 done

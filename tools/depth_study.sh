@@ -6,8 +6,8 @@ out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for d in 0 1 2 3 8; do
-  VRT_BENCH_DEPTH=$d VRT_LIB=$GRAFT_REPO_ROOT/raytracing_amd/libvrt_cnt.so timeout -k 10 100 python3 bench.py --workload $wl --steps 2 --warmup 1 --no-cpu-baseline --frames-8k 0 "${@:3}" > $out/cnt_d$d.json || exit 1
-  VRT_BENCH_DEPTH=$d timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_SALU --output-format csv -d $out/pmc_d$d -- python3 bench.py --workload $wl --steps 2 --warmup 1 --no-cpu-baseline --frames-8k 0 "${@:3}" > $out/pmc_d$d.log 2>&1 || exit 1
+  VRT_BENCH_DEPTH=$d VRT_LIB=$GRAFT_REPO_ROOT/raytracing_amd/libvrt_cnt.so timeout -k 10 100 python3 bench.py --workload $wl --steps 2 --warmup 1 --min-time 0 --no-cpu-baseline --frames-8k 0 "${@:3}" > $out/cnt_d$d.json || exit 1
+  VRT_BENCH_DEPTH=$d timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_SALU --output-format csv -d $out/pmc_d$d -- python3 bench.py --workload $wl --steps 2 --warmup 1 --min-time 0 --no-cpu-baseline --frames-8k 0 "${@:3}" > $out/pmc_d$d.log 2>&1 || exit 1
 done
 python3 - <<PY
 import json, csv, glob, collections

@@ -56,6 +56,19 @@ for bench in sorted(glob.glob(os.path.join(src, "bench_*.json"))):
             fetch = sum(v["FETCH_SIZE"]) / len(v["FETCH_SIZE"])
             write = sum(v["WRITE_SIZE"]) / len(v["WRITE_SIZE"])
             traffic[wl] = (2 * fetch + write) * 1024
+trav_path = os.path.join(dst, "traversal.json")
+trav = json.load(open(trav_path)) if os.path.exists(trav_path) else {}
+for f in sorted(glob.glob(os.path.join(src, "cnt_*.json"))):
+    wl = os.path.basename(f)[4:-5]
+    try:
+        t = json.load(open(f)).get("traversal")
+    except Exception:
+        t = None
+    if t:
+        trav[wl] = {"nodes_per_ray": t["nodes_per_ray"], "prims_per_ray": t["prims_per_ray"]}
+trav["_how"] = ("4-wide nodes entered and primitives tested per intersection query of the workload's frame, counted by a "
+                "-DVRT_COUNT_NODES=1 build of the library (tools/build_variant.sh cnt -DVRT_COUNT_NODES=1)")
+json.dump(trav, open(trav_path, "w"), indent=1)
 traffic["_how"] = ("dominant render kernel of each workload: (2*FETCH_SIZE + WRITE_SIZE)*1024 bytes per dispatch "
                    "from separate rocprofv3 --pmc passes (FETCH_SIZE doubled per the gfx950 correction)")
 json.dump(traffic, open(traffic_path, "w"), indent=1)

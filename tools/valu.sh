@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 k=0
 for o in "$@"; do
   k=$((k+1))
-  timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_SALU --output-format csv -d $out/p$k -- python3 bench.py --workload $wl --steps 2 --warmup 1 --no-cpu-baseline --frames-8k 0 $o > $out/p$k.log 2>&1 || { tail -3 $out/p$k.log; exit 1; }
+  timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_SALU --output-format csv -d $out/p$k -- python3 bench.py --workload $wl --steps 2 --warmup 1 --min-time 0 --no-cpu-baseline --frames-8k 0 $o > $out/p$k.log 2>&1 || { tail -3 $out/p$k.log; exit 1; }
   python3 - "$out/p$k" "$o" <<'PY'
 import csv, glob, collections, sys
 f=glob.glob(sys.argv[1]+"/*/*counter_collection.csv")[0]
