@@ -603,6 +603,65 @@ static col shade(octx* c, ohit hit, oray ray, int depth)
         L.r += wt_ * Lt.r; L.g += wt_ * Lt.g; L.b += wt_ * Lt.b;
         return L;
     }
+    if (m->type == VRT_MAT_MATTE) { /* Material/MatteMaterial.cs:44-75: ambient + Lambert, no shadow test */
+        col L = cmul(cmulf(cd, sh->matte_ka), ambient_occluder_L(c, hit, depth)); /* :49-53 */
+        for (uint32_t i = 0; i < d->n_lights; ++i) {
+            const vrt_light* l = &d->lights[i];
+            v3 lp = V(l->vec[0], l->vec[1], l->vec[2]);
+            v3 wi;
+            if (l->type == VRT_LIGHT_POINT) { /* Light/PointLight.cs:23-34 */
+                v3 tmp = vsub(lp, hit.point);
+                float len = sqrtf(tmp.x * tmp.x + tmp.y * tmp.y + tmp.z * tmp.z);
+                tmp.x /= len; tmp.y /= len; tmp.z /= len;
+                wi = tmp;
+            } else {
+                wi = lp;
+            }
+            float ndotwi = vdot(n, wi);
+            if (ndotwi > 0.f) { /* :69: F * lights[i].L(hit) * ndotwi, left to right */
+                col f = cmulf(cmulf(cd, sh->matte_kd), 0.3183098861837906715f);
+                col lc = C(l->color[0], l->color[1], l->color[2], l->color[3]);
+                L = cadd(L, cmulf(cmul(f, cmulf(lc, l->ls)), ndotwi));
+            }
+        }
+        return L;
+    }
+    if (m->type == VRT_MAT_TRANSPARENT) { /* Material/TransparentMaterial.cs:40-69 */
+        col L = phong_shade(c, hit, ray.d, depth, sh->transp_ka, sh->transp_kd, sh->transp_ks, sh->transp_exp, cd);
+        v3 wo = vneg(ray.d);
+        float ndotwo = vdot(n, wo); /* BRDF/PerfectSpecularBRDF.cs:29-39 */
+        v3 wi = vadd(vneg(wo), vmulf(vmulf(n, 2.f), ndotwo));
+        float fr = sh->transp_kr / fabsf(vdot(n, wi));
+        oray rr = make_ray(hit.point, wi);
+        /* BTDF/PerfectTransmitterBTDF.cs:57-69: Tir() looks at the direction the BTDF was constructed
+         * with, not at the ray being shaded */
+        v3 bwo = vneg(V(sh->transp_ray_dir[0], sh->transp_ray_dir[1], sh->transp_ray_dir[2]));
+        float bci = vdot(n, bwo);
+        float beta = sh->transp_ior;
+        if (bci < 0.f) beta = (float)(1.f / beta);
+        if ((1.f - (1.f - bci * bci) / (beta * beta)) < 0.f) {
+            col Lr = trace_ray(c, rr, depth + 1, hit.prim, VRT_RAY_REFLECT);
+            L.r += Lr.r; L.g += Lr.g; L.b += Lr.b;
+            return L;
+        }
+        /* PerfectTransmitterBTDF.SampleF :32-49 */
+        v3 nn = n;
+        float ci = vdot(nn, wo);
+        float eta = sh->transp_ior;
+        if (ci < 0.f) { ci = -ci; nn = vneg(nn); eta = (float)1.f / eta; }
+        float temp = 1.f - (1.f - ci * ci) / (eta * eta);
+        float c2 = sqrtf(temp);
+        v3 wt = vsub(vdivf(vneg(wo), eta), vmulf(nn, c2 - ci / eta));
+        float ft = sh->transp_kt / (eta * eta) / fabsf(vdot(n, wt));
+        oray tr = make_ray(hit.point, wt);
+        col Lr = trace_ray(c, rr, depth + 1, hit.prim, VRT_RAY_REFLECT);
+        float ar = fabsf(vdot(n, wi));
+        L.r += fr * Lr.r * ar; L.g += fr * Lr.g * ar; L.b += fr * Lr.b * ar;
+        col Lt = trace_ray(c, tr, depth + 1, hit.prim, VRT_RAY_TRANSMIT);
+        float at = fabsf(vdot(n, wt));
+        L.r += ft * Lt.r * at; L.g += ft * Lt.g * at; L.b += ft * Lt.b * at;
+        return L;
+    }
     return phong_shade(c, hit, ray.d, depth, sh->solid_ka, sh->solid_kd, sh->solid_ks, sh->solid_exp, cd);
 }
 

@@ -8,7 +8,7 @@ if it is missing.
 """
 from . import abi  # noqa: F401
 from .params import Params  # noqa: F401
-from .scenes import (Scene, make_camera, teaching_scene, teaching_camera,  # noqa: F401
+from .scenes import (Scene, make_camera, teaching_scene, teaching_camera, teaching_scene_all_materials,  # noqa: F401
                      random_spheres_scene, random_spheres_camera,
                      tessellated_mesh_scene, tessellated_mesh_camera,
                      textured_quad_scene, textured_quad_camera, checker_texture)

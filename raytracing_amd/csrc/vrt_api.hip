@@ -632,6 +632,14 @@ static int cached_offsets(vrt_ctx* c, const float* table, size_t n, const float2
     return VRT_OK;
 }
 
+// The general kernel instantiations (two children per hit, all material classes): refraction with
+// VRT_FIX_DIELECTRIC, or a matte or transparent material in the scene.  Everything else runs the
+// instantiations that know one child per hit and the three shipped material classes.
+static bool two_children(const vrt_ctx* c, const vrt_params* p)
+{
+    return (p->flags & VRT_FIX_DIELECTRIC) != 0 || c->sb.scene.has_transparent != 0 || c->sb.scene.has_matte != 0;
+}
+
 // Validates params and fills DevParams (everything but the offset table pointer).
 static int check_params(vrt_ctx* c, const vrt_params* p, DevParams* out)
 {
@@ -671,6 +679,7 @@ static int check_params(vrt_ctx* c, const vrt_params* p, DevParams* out)
     // pixel on the 10k-sphere frame, +6 % at 4 lanes per pixel on the 1M-triangle frame).
     P.packet = c->opt.packet >= 0 ? c->opt.packet : (P.sample_shift >= 2 ? 1 : 0);
     P.quad_max = c->opt.quad_max >= 0 ? c->opt.quad_max : 16;
+    P.general = two_children(c, p) ? 1 : 0;
     P.offsets = nullptr;
     return VRT_OK;
 }
@@ -684,12 +693,6 @@ static int prepare(vrt_ctx* c, const vrt_params* p, DevParams* out)
         if (rc) return rc;
     }
     return VRT_OK;
-}
-
-// Two children per hit: refraction with VRT_FIX_DIELECTRIC, or a transparent material in the scene.
-static bool two_children(const vrt_ctx* c, const vrt_params* p)
-{
-    return (p->flags & VRT_FIX_DIELECTRIC) != 0 || c->sb.scene.has_transparent != 0;
 }
 
 // Sample slots the wavefront workspace holds at most: a band of rows of the frame is in flight

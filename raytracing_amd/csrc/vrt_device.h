@@ -86,6 +86,7 @@ struct DevParams {
     int xcd_remap;  // renumber blocks so that each XCD works on one contiguous band of tiles
     int sample_shift; // megakernel: log2 of the lanes that share one pixel's samples (0..6)
     int packet;       // tree scenes: rays a wave casts together take the wave-uniform traversal first
+    int general;      // the scene or the flags need the general kernels: two children per hit, matte / transparent materials
     int quad_max;     // tree scenes: a wave with at most this many queries traces them four lanes per ray (0 = never)
 };
 

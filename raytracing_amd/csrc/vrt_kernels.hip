@@ -38,6 +38,10 @@ __global__ __launch_bounds__(VRT_MEGA_THREADS, BVH ? VRT_BVH_WAVES : (SIMPLE ? V
                                               int blocks_x, int n_blocks)
 {
     DevScene S = S_in;
+    // scenes with a matte or transparent material run the TWOCHILD instantiations (vrt_api.hip); P is
+    // what carries the fact, because a modified copy of S, whose `big` array is indexed in a loop,
+    // would live in scratch memory
+    if (!TWOCHILD) P.general = 0;
     if (SIMPLE) { S.n_tri = 0; S.all_aab = 1; S.mat_tex = nullptr; S.n_big = 0; S.tri = nullptr; } // S.box stays: face normals
     unsigned bid = blockIdx.x;
     {   // bijective XCD remap: label = bid % 8 selects a contiguous band of block ids
@@ -132,6 +136,7 @@ __global__ __launch_bounds__(64) void k_pixels(DevScene S, DevCam cam, DevParams
                                                int* __restrict__ hit_out, unsigned long long* ctr)
 {
     int i = blockIdx.x * 64 + threadIdx.x;
+    if (!TWOCHILD) P.general = 0;
     if (!BVH) stage_prims(S);
     Counters C = {0, 0, 0, 0, 0, 0};
 #if VRT_LDS_COUNTERS
@@ -166,6 +171,7 @@ __global__ __launch_bounds__(64) void k_ray(DevScene S, DevParams P, float ox, f
                                             float dz, int depth, float4* __restrict__ rgba_out,
                                             int* __restrict__ hit_out, unsigned long long* ctr)
 {
+    if (!TWOCHILD) P.general = 0;
     if (!BVH) stage_prims(S);
     Counters C = {0, 0, 0, 0, 0, 0};
 #if VRT_LDS_COUNTERS
@@ -205,7 +211,7 @@ hipError_t vrt_launch_mega(const DevScene& S, const DevCam& cam, const DevParams
     int n_blocks = blocks_x * blocks_y;
     if (n_blocks <= 0) return hipSuccess;
     dim3 grid(n_blocks), block(VRT_MEGA_THREADS);
-    const bool simple = !bvh && S.n_tri == 0 && S.all_aab && !S.mat_tex;
+    const bool simple = !bvh && S.n_tri == 0 && S.all_aab && !S.mat_tex && !S.has_matte && !S.has_transparent;
 #define VRT_GO3(B, T, SP, SI) hipLaunchKernelGGL((k_mega<B, T, SP, SI>), grid, block, 0, stream, S, cam, P, rgba, hit_id, ctr, blocks_x, n_blocks)
 #define VRT_GO(B, T) do { if (shift == 0) VRT_GO3(B, T, false, false); else VRT_GO3(B, T, true, false); } while (0)
 #define VRT_GOS(T) do { if (shift == 0) VRT_GO3(false, T, false, true); else VRT_GO3(false, T, true, true); } while (0)

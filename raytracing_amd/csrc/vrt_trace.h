@@ -1017,6 +1017,63 @@ __device__ __forceinline__ f3 phong_shade(const DevScene& S, const DevParams& P,
     return L;
 }
 
+// Material/MatteMaterial.cs:44-75: ambient term and one Lambert term per light that faces the
+// surface; no shadow test, no specular lobe.  The light term is F * L * ndotwi, left to right.
+template <bool BVH, bool RECORD, class OCC>
+__device__ __forceinline__ f3 matte_shade(const DevScene& S, const DevParams& P, f3 point, f3 n, int prim, int depth,
+                                          f3 cd, Counters& C, Recorder& R, OCC& occ)
+{
+    f3 L = (cd * S.sh.matte_ka) * ambient_L<BVH, RECORD>(S, P, point, n, prim, depth, C, R, occ);
+    for (int i = 0; i < S.n_lights; ++i) {
+        const DevLight& l = S.lights[i];
+        f3 lp = mk3(l.vx, l.vy, l.vz);
+        f3 wi;
+        if (l.type == VRT_LIGHT_POINT) {
+            f3 tmp = lp - point;
+            float len = sqrtf(tmp.x * tmp.x + tmp.y * tmp.y + tmp.z * tmp.z);
+            wi = mk3(tmp.x / len, tmp.y / len, tmp.z / len);
+        } else {
+            wi = lp;
+        }
+        float ndotwi = dot3(n, wi);
+        if (ndotwi > 0.f) {
+            f3 f = (cd * S.sh.matte_kd) * 0.3183098861837906715f;
+            L = L + (f * (mk3(l.cr, l.cg, l.cb) * l.ls)) * ndotwi;
+        }
+    }
+    return L;
+}
+
+// Material/TransparentMaterial.cs:44-66 after the Phong term: the reflected ray and, unless
+// PerfectTransmitterBTDF.Tir says total internal reflection, the transmitted ray with their weights.
+// Tir (BTDF/PerfectTransmitterBTDF.cs:57-69) looks at the direction the BTDF was constructed with
+// (sh.transp_ray_dir), SampleF (:32-49) at the ray being shaded.
+__device__ __forceinline__ int transparent_children(const vrt_shading& sh, f3 n, f3 d, f3& d0, f3& w0, f3& d1, f3& w1)
+{
+    const f3 wo = -d;
+    const float ndotwo = dot3(n, wo);
+    const f3 wi = (-wo) + (n * 2.f) * ndotwo;
+    d0 = normalize3(wi);
+    const f3 bwo = -mk3(sh.transp_ray_dir[0], sh.transp_ray_dir[1], sh.transp_ray_dir[2]);
+    const float bci = dot3(n, bwo);
+    float beta = sh.transp_ior;
+    if (bci < 0.f) beta = 1.f / beta;
+    if ((1.f - (1.f - bci * bci) / (beta * beta)) < 0.f) { w0 = mk3(1.f, 1.f, 1.f); return 1; }
+    const float fr = sh.transp_kr / fabsf(dot3(n, wi));
+    f3 nn = n;
+    float ci = dot3(nn, wo);
+    float eta = sh.transp_ior;
+    if (ci < 0.f) { ci = -ci; nn = -nn; eta = 1.f / eta; }
+    const float temp = 1.f - (1.f - ci * ci) / (eta * eta);
+    const float c2 = sqrtf(temp);
+    const f3 wt = ((-wo) / eta) - nn * (c2 - ci / eta);
+    const float ft = sh.transp_kt / (eta * eta) / fabsf(dot3(n, wt));
+    const float wr = fr * fabsf(dot3(n, wi)), wtt = ft * fabsf(dot3(n, wt));
+    w0 = mk3(wr, wr, wr);
+    d1 = normalize3(wt); w1 = mk3(wtt, wtt, wtt);
+    return 2;
+}
+
 // BRDF/FresnelReflectorBRDF.cs:14-39 (only with VRT_FIX_DIELECTRIC)
 __device__ __forceinline__ float fresnel_kr(f3 normal, f3 direction, float eta_in, float eta_out)
 {
@@ -1137,6 +1194,12 @@ __device__ __forceinline__ void shade_hit(const DevScene& S, const DevParams& P,
                 n_child = 2; d1 = normalize3(wt); w1 = mk3(wtt, wtt, wtt);
             }
         }
+    } else if (P.general && mtype == VRT_MAT_MATTE) {
+        A = matte_shade<BVH, RECORD>(S, P, point, n, h.prim, depth, cd, C, R, occ);
+    } else if (P.general && mtype == VRT_MAT_TRANSPARENT) {
+        A = phong_shade<BVH, RECORD>(S, P, point, n, h.prim, d, depth, sh.transp_ka, sh.transp_kd,
+                                       sh.transp_ks, sh.transp_exp, cd, C, R, occ);
+        n_child = transparent_children(sh, n, d, d0, w0, d1, w1);
     } else {
         A = phong_shade<BVH, RECORD>(S, P, point, n, h.prim, d, depth, sh.solid_ka, sh.solid_kd,
                                        sh.solid_ks, sh.solid_exp, cd, C, R, occ);
@@ -1294,7 +1357,7 @@ __device__ __forceinline__ float4 trace_pixel_dev(const DevScene& S, const DevCa
 // on different material classes, which scalar kernel arguments cannot serve.
 struct LdsScene {
     DevLight lights[VRT_MAX_LIGHTS];
-    float4 matk[4]; // (ka, kd, ks, exp) by VRT_MAT_* class
+    float4 matk[8]; // (ka, kd, ks, exp) by VRT_MAT_* class
 };
 
 // Fills the LDS copy: lights one dword per lane from device memory, material constants from
@@ -1311,6 +1374,9 @@ __device__ __forceinline__ void stage_scene(const DevScene& S, LdsScene* lds)
         lds->matk[VRT_MAT_SOLID] = make_float4(sh.solid_ka, sh.solid_kd, sh.solid_ks, sh.solid_exp);
         lds->matk[VRT_MAT_METAL] = make_float4(sh.metal_ka, sh.metal_kd, sh.metal_ks, sh.metal_exp);
         lds->matk[VRT_MAT_DIELECTRIC] = make_float4(sh.glass_ka, sh.glass_kd, sh.glass_ks, sh.glass_exp);
+        lds->matk[VRT_MAT_MATTE] = make_float4(sh.matte_ka, sh.matte_kd, 0.f, 1.f);
+        lds->matk[VRT_MAT_TRANSPARENT] = make_float4(sh.transp_ka, sh.transp_kd, sh.transp_ks, sh.transp_exp);
+        lds->matk[6] = lds->matk[7] = lds->matk[0];
     }
     __syncthreads();
 }
@@ -1320,7 +1386,7 @@ enum { ST_SAMPLE = 0, ST_CLOSEST = 1, ST_AO = 2, ST_LIGHTS = 3, ST_SHADOW = 4, S
 struct MatK { float ka, kd, ks, ex; };
 __device__ __forceinline__ MatK material_consts(const LdsScene* lds, int mtype)
 {
-    float4 v = lds->matk[mtype & 3];
+    float4 v = lds->matk[mtype & 7];
     MatK k; k.ka = v.x; k.kd = v.y; k.ks = v.z; k.ex = v.w;
     return k;
 }
@@ -1338,9 +1404,10 @@ __device__ __forceinline__ f3 light_wi(const DevLight& l, f3 point)
 }
 
 // One unshadowed light's term of Material/PhongMaterial.cs:77-84.
-__device__ __forceinline__ f3 light_term(const DevLight& l, f3 wi, float ndotwi, f3 n, f3 wo, f3 cd, MatK k)
+__device__ __forceinline__ f3 light_term(const DevLight& l, f3 wi, float ndotwi, f3 n, f3 wo, f3 cd, MatK k, bool matte = false)
 {
     f3 diff = (cd * k.kd) * 0.3183098861837906715f;
+    if (matte) return (diff * (mk3(l.cr, l.cg, l.cb) * l.ls)) * ndotwi;   // Material/MatteMaterial.cs:69
     float spec = 0.f;
     if (!(k.ks == 0.f && k.ex >= 0.f)) { // see phong_shade
         float nda = dot3(n, wo);
@@ -1459,7 +1526,7 @@ __device__ __forceinline__ f3 trace_samples_sm(const DevScene& S, const DevCam& 
                 float ndotwi = dot3(n, wi);
                 bool shadow_query = false;
                 if (ndotwi > 0.f) {
-                    if (l.cast) {
+                    if (l.cast && mtype != VRT_MAT_MATTE) {   // the matte material asks for no shadow test
                         f3 sd = normalize3(wi);
                         f3 loc = l.type == VRT_LIGHT_POINT ? mk3(l.vx, l.vy, l.vz) : mk3(l.lx, l.ly, l.lz);
                         dist = mag3(loc - qo);
@@ -1470,7 +1537,7 @@ __device__ __forceinline__ f3 trace_samples_sm(const DevScene& S, const DevCam& 
                         }
                     }
                     if (!shadow_query)
-                        A = A + light_term(l, wi, ndotwi, n, -rd, cd, material_consts(lds, mtype));
+                        A = A + light_term(l, wi, ndotwi, n, -rd, cd, material_consts(lds, mtype), mtype == VRT_MAT_MATTE);
                 }
                 if (!shadow_query) light++;
             } else if (st == ST_SHADOW) {
@@ -1487,7 +1554,9 @@ __device__ __forceinline__ f3 trace_samples_sm(const DevScene& S, const DevCam& 
                 L = L + T * A;
                 int n_child = 0;
                 f3 d0 = mk3(0.f, 0.f, 0.f), w0 = d0, d1 = d0, w1 = d0;
-                if (mtype == VRT_MAT_METAL || mtype == VRT_MAT_DIELECTRIC) {
+                if (TWOCHILD && mtype == VRT_MAT_TRANSPARENT) {
+                    n_child = transparent_children(sh, n, rd, d0, w0, d1, w1);
+                } else if (mtype == VRT_MAT_METAL || mtype == VRT_MAT_DIELECTRIC) {
                     f3 wo = -rd;
                     float ndotwo = dot3(n, wo);
                     f3 wi = (-wo) + (n * 2.f) * ndotwo;

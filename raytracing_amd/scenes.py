@@ -228,6 +228,20 @@ def teaching_scene(point_light=True):
     return s
 
 
+def teaching_scene_all_materials(transparent_ray_dir=(0.0, 0.0, 0.0)):
+    """The teaching diorama with the two material classes the reference defines but never
+    instantiates put on three of its spheres: Material/MatteMaterial.cs on the blue and the green
+    one, Material/TransparentMaterial.cs on the large front sphere.  transparent_ray_dir is the
+    direction PerfectTransmitterBTDF keeps from its constructor (BTDF/PerfectTransmitterBTDF.cs:17-20)."""
+    s = teaching_scene()
+    s.materials["type"][1] = abi.VRT_MAT_MATTE        # Blue
+    s.materials["type"][4] = abi.VRT_MAT_MATTE        # Green
+    glassy = s.add_material("Transparent", abi.VRT_MAT_TRANSPARENT, (0.65, 0.45, 0.0))
+    s.spheres["material"][1] = glassy
+    s.shading.transp_ray_dir[:] = [float(x) for x in transparent_ray_dir]
+    return s
+
+
 def teaching_camera(width=200, height=200):
     """Eye/RayCaster at (1.45, 2, 2.5) (VisualRayTrace.unity:45575-45590,13735-13748) and the
     viewport quad at (3, 2.05, 2.5), rot Y 90 deg, scale (2,1,1) (:2652-2669): P0 = (3, 1.55,

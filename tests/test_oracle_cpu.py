@@ -194,6 +194,39 @@ def test_hand_derived_shading_values(oracle_mod):
     assert np.allclose(rgba3[:3], raw / max(1.0, raw.max()), atol=1e-5)
 
 
+def test_hand_derived_matte_and_transparent(oracle_mod):
+    """The two material classes the reference defines but never instantiates, on the same set-up:
+    MatteMaterial = ambient + Lambert without a shadow test (Material/MatteMaterial.cs:44-75);
+    TransparentMaterial straight down the normal: reflection weight kr, transmission weight
+    kt / ior^2 straight through (Material/TransparentMaterial.cs:40-69, BTDF/PerfectTransmitterBTDF.cs:32-49)."""
+    s = ra.Scene()
+    m = s.add_material("M", abi.VRT_MAT_MATTE, (1.0, 0.5, 0.25))
+    s.add_sphere((0, 0, 0), 1.0, m)
+    s.add_light(abi.VRT_LIGHT_DIRECTIONAL, (0, 1, 0), ls=1.0, cast_shadows=True, location=(0, 50, 0))
+    cam = ra.make_camera((0, 5, 0), (-0.5, 4, -0.5), (1, 0, 0), (0, 0, 1), 2, 2)
+    prm = ra.Params(spp=1, max_depth=3)
+    cd = np.float32([1.0, 0.5, 0.25])
+    lambert = np.float32(0.5) * cd * np.float32(0.3183098861837906715)
+    rgba, hit, segs, n, rays = oracle_mod.trace_pixel(s, cam, prm.c, 1, 1, -1, 16)
+    assert np.allclose(rgba[:3], np.float32(0.5) * cd + lambert, atol=1e-6)
+    assert rays[abi.VRT_RAY_SHADOW] == 0 and rays[abi.VRT_RAY_AO] == 1   # no shadow ray although the light casts shadows
+    # transparent, straight down the normal at the top of the sphere
+    s.materials["type"][0] = abi.VRT_MAT_TRANSPARENT
+    rgba3, hit3, segs3, n3, rays3 = oracle_mod.trace_pixel(s, cam, prm.c, 1, 1, -1, 16)
+    sky_up, sky_down = np.float32([0.5, 0.7, 1.0]), np.float32([1.0, 1.0, 1.0])
+    phong = np.float32(0.5) * cd + lambert + np.float32(0.5)          # ks * 1^2000
+    raw = phong + np.float32(0.1) * sky_up + np.float32(0.9 / 2.25) * sky_down
+    assert np.allclose(rgba3[:3], raw / max(1.0, raw.max()), atol=1e-5)
+    assert rays3[abi.VRT_RAY_REFLECT] == 1 and rays3[abi.VRT_RAY_TRANSMIT] == 1
+    # PerfectTransmitterBTDF.Tir looks at the direction it was constructed with: (0, 1, 0) makes it
+    # "inside, grazing" for this normal (n.wo = -1 is not grazing) -> still refraction; (1, 0.2, 0) -> TIR
+    s.shading.transp_ray_dir[:] = (1.0, 0.2, 0.0)
+    rgba4, _, _, _, rays4 = oracle_mod.trace_pixel(s, cam, prm.c, 1, 1, -1, 16)
+    raw = phong + sky_up                                                # reflection with weight 1
+    assert np.allclose(rgba4[:3], raw / max(1.0, raw.max()), atol=1e-5)
+    assert rays4[abi.VRT_RAY_REFLECT] == 1 and rays4[abi.VRT_RAY_TRANSMIT] == 0
+
+
 def test_primary_miss_is_black_and_ray_classes(oracle_mod):
     scene, cam = ra.teaching_scene(), ra.teaching_camera(40, 40)
     prm = ra.Params(spp=1, max_depth=2)

@@ -44,7 +44,23 @@ def cases():
         ra.teaching_scene(), ra.teaching_camera(160, 90),
         ra.Params(spp=1, max_depth=6,
                   flags=abi.VRT_FIX_DIELECTRIC | abi.VRT_FIX_PRIMARY_SKY | abi.VRT_FIX_AO_BASIS))
+    out["matte_transparent_160x90_2spp_d6"] = (
+        ra.teaching_scene_all_materials(), ra.teaching_camera(160, 90),
+        ra.Params(spp=2, offsets=host_free_table(2), seed=3, max_depth=6))
+    out["transparent_tir_96x54_d5"] = (
+        ra.teaching_scene_all_materials(transparent_ray_dir=(0.0, 0.99, 0.14)), ra.teaching_camera(96, 54),
+        ra.Params(spp=1, max_depth=5))
     return out
+
+
+def host_free_table(spp):
+    """A small fixed sampler table (no library needed): offsets on a diagonal, two sets."""
+    import numpy as np
+    t = np.zeros((2, spp, 2), np.float32)
+    for k in range(2):
+        for i in range(spp):
+            t[k, i] = (0.003 * (i + 1) * (k + 1), -0.002 * (i + 1))
+    return t
 
 
 def main():
