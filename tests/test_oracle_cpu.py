@@ -263,3 +263,42 @@ def test_csharp_binding_agrees_with_the_header():
     assert imported and imported <= declared, imported - declared
     m = re.search(r"FixPrimarySky = (\d+), FixAoBasis = (\d+), FixDielectric = (\d+)", cs)
     assert [int(x) for x in m.groups()] == [abi.VRT_FIX_PRIMARY_SKY, abi.VRT_FIX_AO_BASIS, abi.VRT_FIX_DIELECTRIC]
+    assert set(abi.EXPORTS) - {"vrt_abi_version"} <= imported | {"vrt_abi_version"}, set(abi.EXPORTS) - imported
+    m = re.search(r"MatMatte = (\d+), MatTransparent = (\d+)", cs)
+    assert [int(x) for x in m.groups()] == [abi.VRT_MAT_MATTE, abi.VRT_MAT_TRANSPARENT]
+
+    # every struct: same fields in the same order, compared as a flat list of 4-byte words / pointers
+    words = {"int": 1, "uint": 1, "float": 1, "Vector3": 3, "Color": 4, "IntPtr": "p", "ulong": 2, "Shading": None}
+
+    def cs_layout(name):
+        body = re.search(r"struct %s\s*\{(.*?)\}" % name, cs, re.S).group(1)
+        out = []
+        for typ, names in re.findall(r"public\s+(?:fixed\s+)?(\w+)\s+([^;]+);", body):
+            for n in names.split(","):
+                n = n.strip()
+                arr = re.search(r"\[(\d+)\]", n)
+                k = int(arr.group(1)) if arr else 1
+                if typ == "Shading":
+                    out += cs_layout("Shading")
+                elif words[typ] == "p":
+                    out += ["p"] * k
+                else:
+                    out += ["w"] * (words[typ] * k)
+        return out
+
+    def c_layout(ct):
+        out = []
+        for fname, ftype in ct._fields_:
+            if issubclass(ftype, C.Structure):
+                out += c_layout(ftype)
+            elif issubclass(ftype, (C._Pointer, C.c_void_p)) or ftype is C.c_char_p:
+                out += ["p"]
+            else:
+                out += ["w"] * (C.sizeof(ftype) // 4)
+        return out
+
+    for cs_name, ct in (("Sphere", abi.vrt_sphere), ("Box", abi.vrt_box), ("Material", abi.vrt_material),
+                        ("Light", abi.vrt_light), ("Shading", abi.vrt_shading), ("Texture", abi.vrt_texture),
+                        ("SceneDesc", abi.vrt_scene_desc), ("Camera", abi.vrt_camera), ("PathSeg", abi.vrt_path_seg),
+                        ("Params", abi.vrt_params), ("Stats", abi.vrt_stats)):
+        assert cs_layout(cs_name) == c_layout(ct), cs_name

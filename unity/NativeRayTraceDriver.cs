@@ -15,6 +15,7 @@ public sealed class NativeRayTraceDriver : MonoBehaviour
     public AASamplingStrategy SamplingMethod = AASamplingStrategy.Hammersley;
     public int SampleSetCount = 83;
     public uint Seed = 1;
+    public int Gpus = 1;
 
     IntPtr _ctx = IntPtr.Zero;
     VrtNative.Params _prm;
@@ -28,7 +29,9 @@ public sealed class NativeRayTraceDriver : MonoBehaviour
     public void Init(Vector3 rayOrigin, ViewPortPlaneInformation viewPort, TextureInformation texture)
     {
         if (VrtNative.vrt_abi_version() != VrtNative.AbiVersion) throw new InvalidOperationException("libvrt: ABI version mismatch");
-        VrtNative.Check(IntPtr.Zero, VrtNative.vrt_create(0, out _ctx), "vrt_create");
+        // Gpus > 1: the same calls on a context that spans GPUs 0 .. Gpus-1 of the node (blocking vrt_render only)
+        if (Gpus > 1) VrtNative.Check(IntPtr.Zero, VrtNative.vrt_create_multi(Gpus, null, out _ctx), "vrt_create_multi");
+        else VrtNative.Check(IntPtr.Zero, VrtNative.vrt_create(0, out _ctx), "vrt_create");
         RebuildScene();
         int dim = texture.TextureDimension;
         var cam = new VrtNative.Camera { origin = rayOrigin, p0 = viewPort.PlaneBorderPoints[0], xAxis = viewPort.PlaneXAxis,
@@ -65,6 +68,26 @@ public sealed class NativeRayTraceDriver : MonoBehaviour
         _frameInFlight = true;
     }
 
+    /// Continuous mode with the frame delivered in strip sets: PollParts says how many have landed in
+    /// PixelColorData, and the caller uploads only their rows (Texture2D.SetPixels(x, y, w, h, ...) per
+    /// strip) instead of SetPixels + Apply of the whole texture (:461-477).
+    public int PartsInFlight { get; private set; }
+    public void StartFrameInParts(int nParts)
+    {
+        if (_frameInFlight) return;
+        VrtNative.Check(_ctx, VrtNative.vrt_render_begin_parts(_ctx, ref _prm, _pixelsPin.AddrOfPinnedObject(), _idsPin.AddrOfPinnedObject(), nParts),
+                        "vrt_render_begin_parts");
+        _frameInFlight = true; PartsInFlight = nParts;
+    }
+
+    /// Strip sets finished so far; part k holds the rows r with (r / tileRows) % nParts == k.
+    public int PollParts()
+    {
+        if (!_frameInFlight || PartsInFlight == 0) return 0;
+        VrtNative.Check(_ctx, VrtNative.vrt_render_poll_parts(_ctx, out int done), "vrt_render_poll_parts");
+        return done;
+    }
+
     /// True once PixelColorData holds the frame; the caller then runs UpdateRenderTexture (:461-477).
     public bool PollFrame()
     {
@@ -72,7 +95,7 @@ public sealed class NativeRayTraceDriver : MonoBehaviour
         VrtNative.Check(_ctx, VrtNative.vrt_render_poll(_ctx, out int done), "vrt_render_poll");
         if (done == 0) return false;
         VrtNative.Check(_ctx, VrtNative.vrt_render_end(_ctx, out VrtNative.Stats _), "vrt_render_end");
-        _frameInFlight = false;
+        _frameInFlight = false; PartsInFlight = 0;
         return true;
     }
 

@@ -1,4 +1,4 @@
-// P/Invoke binding of libvrt.so (include/vrt.h, ABI version 4) for the Unity host of
+// P/Invoke binding of libvrt.so (include/vrt.h, ABI version 5) for the Unity host of
 // VisualRayTrace.  Goes to Assets/Scripts/RayTracer/Native/; libvrt.so goes to
 // Assets/Plugins/x86_64/.  Every struct is blittable and laid out like its C counterpart:
 // Vector3 = 3 floats, Color = 4 floats, pointers as IntPtr.
@@ -13,9 +13,11 @@ public static class VrtNative
 {
     const string Lib = "vrt";
     const CallingConvention CC = CallingConvention.Cdecl;
-    public const int AbiVersion = 4;
+    public const int AbiVersion = 5;
 
     public const int MatSolid = 1, MatMetal = 2, MatDielectric = 3;         // RayTraceUtility.MaterialType
+    public const int MatMatte = 4, MatTransparent = 5;                      // Material/MatteMaterial.cs, Material/TransparentMaterial.cs
+    public const int MaxLights = 8, MaxGpus = 16, MaxParts = 64;
     public const int LightDirectional = 0, LightPoint = 1;
     public const uint FixPrimarySky = 1, FixAoBasis = 2, FixDielectric = 4;
     public const uint OutLinearRgb = 1u << 8;   // vrt_render_device only: 3 floats per pixel before MaxToOne
@@ -32,7 +34,9 @@ public static class VrtNative
         public float solidKa, solidKd, solidKs, solidExp;
         public float metalKa, metalKd, metalKs, metalExp, metalKr; public Color metalCr;
         public float glassKa, glassKd, glassKs, glassExp, glassEtaIn, glassEtaOut;
-        public Color aoMinAmount; public float aoLs; public Color aoColor; }
+        public Color aoMinAmount; public float aoLs; public Color aoColor;
+        public float matteKa, matteKd;
+        public float transpKa, transpKd, transpKs, transpExp, transpIor, transpKr, transpKt; public Vector3 transpRayDir; }
     [StructLayout(LayoutKind.Sequential)] public struct Texture { public int width, height, wrap; public IntPtr rgba; }
     [StructLayout(LayoutKind.Sequential)] public struct SceneDesc {
         public uint nSpheres; public IntPtr spheres; public uint nBoxes; public IntPtr boxes;
@@ -51,7 +55,14 @@ public static class VrtNative
 
     [DllImport(Lib, CallingConvention = CC)] public static extern int vrt_abi_version();
     [DllImport(Lib, CallingConvention = CC)] public static extern int vrt_create(int device, out IntPtr ctx);
+    [DllImport(Lib, CallingConvention = CC)] public static extern int vrt_create_multi(int nGpus, int[] devices, out IntPtr ctx);
     [DllImport(Lib, CallingConvention = CC)] public static extern int vrt_destroy(IntPtr ctx);
+    [DllImport(Lib, CallingConvention = CC)] public static extern int vrt_set_option(IntPtr ctx, [MarshalAs(UnmanagedType.LPStr)] string name, long value);
+    // page-locked frame memory: wrap the pointer of vrt_host_alloc in a NativeArray<Color> for PixelColorData
+    [DllImport(Lib, CallingConvention = CC)] public static extern int vrt_host_alloc(IntPtr ctx, ulong bytes, out IntPtr buffer);
+    [DllImport(Lib, CallingConvention = CC)] public static extern int vrt_host_free(IntPtr ctx, IntPtr buffer);
+    [DllImport(Lib, CallingConvention = CC)] public static extern int vrt_host_register(IntPtr ctx, IntPtr buffer, ulong bytes);
+    [DllImport(Lib, CallingConvention = CC)] public static extern int vrt_host_unregister(IntPtr ctx, IntPtr buffer);
     [DllImport(Lib, CallingConvention = CC)] public static extern IntPtr vrt_last_error(IntPtr ctx);
     [DllImport(Lib, CallingConvention = CC)] public static extern void vrt_shading_defaults(out Shading s);
     [DllImport(Lib, CallingConvention = CC)] public static extern void vrt_params_defaults(out Params p);
@@ -59,6 +70,8 @@ public static class VrtNative
     [DllImport(Lib, CallingConvention = CC)] public static extern int vrt_set_camera(IntPtr ctx, ref Camera cam);
     [DllImport(Lib, CallingConvention = CC)] public static extern int vrt_render(IntPtr ctx, ref Params p, [Out] Color[] rgba, [Out] int[] hitIds, out Stats stats);
     [DllImport(Lib, CallingConvention = CC)] public static extern int vrt_render_begin(IntPtr ctx, ref Params p, IntPtr rgba, IntPtr hitIds);
+    [DllImport(Lib, CallingConvention = CC)] public static extern int vrt_render_begin_parts(IntPtr ctx, ref Params p, IntPtr rgba, IntPtr hitIds, int nParts);
+    [DllImport(Lib, CallingConvention = CC)] public static extern int vrt_render_poll_parts(IntPtr ctx, out int partsDone);
     [DllImport(Lib, CallingConvention = CC)] public static extern int vrt_render_poll(IntPtr ctx, out int done);
     [DllImport(Lib, CallingConvention = CC)] public static extern int vrt_render_end(IntPtr ctx, out Stats stats);
     // frames that stay in GPU memory (stream = a hipStream_t or IntPtr.Zero); _noalloc allocates nothing (megakernel only)

@@ -109,7 +109,8 @@ public sealed class VrtSceneMarshaller
             desc.nVertices = (uint)_vertices.Count; desc.vertices = Pin(_vertices.ToArray());
             desc.nTriangles = (uint)(_indices.Count / 3); desc.indices = Pin(_indices.ToArray()); desc.triMaterial = Pin(_triMaterial.ToArray());
             desc.nMaterials = (uint)_materials.Count; desc.materials = Pin(_materials.ToArray());
-            desc.nLights = (uint)Math.Min(_lights.Count, 8); desc.lights = Pin(_lights.ToArray());
+            // all of them: more than VrtNative.MaxLights is reported by vrt_set_scene (VRT_ERR_CAPACITY), not cut silently
+            desc.nLights = (uint)_lights.Count; desc.lights = Pin(_lights.ToArray());
             VrtNative.vrt_shading_defaults(out desc.shading);
             // the sliders of the options canvas write these statics (OptionsCanvas/CanvasSettings.cs:276-325)
             desc.shading.metalKa = RayTraceUtility.Metal_KA; desc.shading.metalKd = RayTraceUtility.Metal_KD;
