@@ -5,6 +5,8 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <string>
+#include <vector>
 
 #include "vrt_host.hpp"
 
@@ -114,8 +116,82 @@ static void gpu_checks()
     CHECK(threw);
 }
 
+// test_host --dump DIR: what the mirrored classes deliver for the teaching scene, written out so that
+// a test can hold it against the CPU oracle: the frame of RenderAll (PixelColorData, primary hit
+// ids, ray counts), and for a few pixels what DoRayTraceArchitecture returns, the recorded ray
+// tree and the polyline RT_rec_points.  Also the sampler table and the scene as handed to the library.
+template <class T>
+static void dump(const std::string& dir, const char* name, const T* data, size_t n)
+{
+    FILE* f = std::fopen((dir + "/" + name).c_str(), "wb");
+    if (!f) { std::printf("FAIL: cannot write %s/%s\n", dir.c_str(), name); ++failures; return; }
+    if (n) std::fwrite(data, sizeof(T), n, f);
+    std::fclose(f);
+}
+
+static void dump_run(const std::string& dir)
+{
+    Device dev(0);
+    WorldInformation w;
+    build_teaching_world(w);
+    w.MaxDepth = 5;
+    RayTracerUnity rt(dev, w);
+    rt.rayOrigin = Vector3{1.45f, 2, 2.5f};
+    rt.planeP0 = Vector3{3, 1.55f, 3.5f};
+    rt.planeXAxis = Vector3{0, 0, -2};
+    rt.planeYAxis = Vector3{0, 1, 0};
+    rt.textureWidth = 96; rt.textureHeight = 64;
+    rt.SampleSize = 4; rt.SampleSetCount = 5;
+    rt.SamplingMethod = AASamplingStrategy::Jittered;
+    rt.Start();
+    rt.RenderAll();
+    vrt_scene_desc d = w.Desc();
+    dump(dir, "spheres.bin", d.spheres, d.n_spheres);
+    dump(dir, "boxes.bin", d.boxes, d.n_boxes);
+    dump(dir, "materials.bin", d.materials, d.n_materials);
+    dump(dir, "lights.bin", d.lights, d.n_lights);
+    dump(dir, "shading.bin", &d.shading, 1);
+    dump(dir, "frame.bin", &rt.PixelColorData()[0].r, rt.PixelColorData().size() * 4);
+    dump(dir, "ids.bin", rt.PrimaryHitIds().data(), rt.PrimaryHitIds().size());
+    dump(dir, "rays.bin", rt.Stats().rays, (size_t)VRT_RAY_CLASSES);
+    const int probe[6][2] = {{32, 48}, {10, 10}, {40, 70}, {63, 95}, {20, 30}, {35, 40}};
+    std::vector<int32_t> meta;          // per probe: h, v, hit id, segments, polyline points
+    std::vector<float> colors, points;
+    std::vector<vrt_path_seg> segs;
+    for (auto& p : probe) {
+        Color c = rt.DoRayTraceArchitecture(p[0], p[1]);
+        std::vector<Vector3> pts = rt.RT_rec_points();
+        meta.push_back(p[0]); meta.push_back(p[1]);
+        meta.push_back(rt.PrimaryHitIds()[(size_t)p[0] * 96 + p[1]]);
+        meta.push_back((int32_t)rt.RT_rec_segments().size()); meta.push_back((int32_t)pts.size());
+        colors.push_back(c.r); colors.push_back(c.g); colors.push_back(c.b); colors.push_back(c.a);
+        segs.insert(segs.end(), rt.RT_rec_segments().begin(), rt.RT_rec_segments().end());
+        for (const Vector3& q : pts) { points.push_back(q.x); points.push_back(q.y); points.push_back(q.z); }
+    }
+    dump(dir, "probe_meta.bin", meta.data(), meta.size());
+    dump(dir, "probe_colors.bin", colors.data(), colors.size());
+    dump(dir, "probe_segs.bin", segs.data(), segs.size());
+    dump(dir, "probe_points.bin", points.data(), points.size());
+    // the tracer slot: WhittedTracer.TraceRay(ray, depth) for a few rays
+    WhittedTracer tracer(dev, w, w.MaxDepth, 30.f);
+    const float dirs[4][3] = {{1.55f, 0.f, 0.f}, {1.55f, -0.45f, 0.3f}, {0.f, 1.f, 0.f}, {1.55f, -0.2f, -0.6f}};
+    std::vector<float> ray_out;
+    for (auto& q : dirs)
+        for (int depth = 0; depth < 3; ++depth) {
+            Ray r; r.origin = rt.rayOrigin; r.direction = Vector3{q[0], q[1], q[2]};
+            Color c = tracer.TraceRay(r, depth);
+            ray_out.push_back(c.r); ray_out.push_back(c.g); ray_out.push_back(c.b); ray_out.push_back((float)tracer.LastHit());
+        }
+    dump(dir, "rays_traced.bin", ray_out.data(), ray_out.size());
+}
+
 int main(int argc, char** argv)
 {
+    if (argc > 2 && std::strcmp(argv[1], "--dump") == 0) {
+        try { dump_run(argv[2]); } catch (const Error& e) { std::printf("FAIL: libvrt error %d: %s\n", e.code, e.what()); ++failures; }
+        std::printf(failures ? "test_host: %d failure(s)\n" : "test_host: OK\n", failures);
+        return failures ? 1 : 0;
+    }
     bool cpu_only = argc > 1 && std::strcmp(argv[1], "--cpu") == 0;
     cpu_checks();
     if (cpu_only) {
