@@ -196,6 +196,48 @@ def cpu_baseline(scene, cam, prm):
             "nproc": nproc, "cores_allowed": allowed, "omp_num_threads_env": os.environ.get("OMP_NUM_THREADS")}
 
 
+def in_library_multi(n_gpus, workload, steps):
+    """The same split behind the C ABI (vrt_create_multi: one host thread per GPU, strips gathered to
+    the first GPU with RCCL, assembled and tone-mapped there, frame copied to page-locked host
+    memory), measured in a child process of its own after the ranks of this job have gone idle:
+    the call a one-process host such as Unity makes.  Returns a dict or a short reason."""
+    import subprocess
+    code = r"""
+import json, sys, time
+import numpy as np
+sys.path.insert(0, %r)
+import bench
+import raytracing_amd as ra
+from raytracing_amd import abi, host
+n, wl, steps = %d, %r, %d
+scene, cam, offsets, kw, label = bench.build_workload(wl, n)
+one = host.Context(0)
+one.set_scene(scene); one.set_camera(cam)
+prm = ra.Params(offsets=offsets, **kw)
+want, want_hit, st1 = one.render(prm)
+one.close()
+m = host.Context(devices=list(range(n)))
+m.set_scene(scene); m.set_camera(cam)
+rgba, hit = m.host_alloc(want.shape, np.float32), m.host_alloc(want_hit.shape, np.int32)
+m.render(prm, rgba=rgba, hit=hit)
+ts = []
+for _ in range(steps):
+    t0 = time.perf_counter(); _, _, st = m.render(prm, rgba=rgba, hit=hit); ts.append((time.perf_counter() - t0) * 1e3)
+q = float(sum(st.rays[1:]))
+print(json.dumps({"workload": label, "gpus": n, "ms_per_frame_host": float(np.median(ts)), "gpu_ms": st.gpu_ms,
+                  "Mrays_per_s": q / float(np.median(ts)) / 1e3,
+                  "frame_equals_one_gpu": bool(np.array_equal(rgba, want, equal_nan=True) and np.array_equal(hit, want_hit)),
+                  "rays_equal_one_gpu": list(st.rays) == list(st1.rays)}))
+""" % (ROOT, n_gpus, workload, steps)
+    try:
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=240)
+        if out.returncode != 0:
+            return {"error": (out.stderr or out.stdout)[-400:]}
+        return json.loads(out.stdout.strip().splitlines()[-1])
+    except Exception as e:   # the headline measurement must not depend on this
+        return {"error": repr(e)[-400:]}
+
+
 def scaling_8k(local_rank, world, rank, dev, cdev, rehearsal, frames, tile_rows, mode):
     """The configuration the scaling target is stated on: 10k random spheres at 7680x4320,
     64 samples per pixel, depth 8, ONE frame of fixed size split into 8-row strips over the
@@ -294,6 +336,8 @@ def main():
     ap.add_argument("--frames-8k", type=int, default=2,
                     help="frames of the 8K x 64 spp strong-scaling measurement reported as `scaling_8k` "
                          "(0 = skip it)")
+    ap.add_argument("--no-in-library-multi", action="store_true",
+                    help="with N > 1: skip the measurement of vrt_create_multi (one process driving all N GPUs)")
     ap.add_argument("--min-time", type=float, default=0.5,
                     help="the timed region of --steps steps is repeated until this many seconds are timed")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
@@ -360,6 +404,7 @@ def main():
     # render stream only waits for the gather itself before it reuses a strip buffer.
     side = torch.cuda.Stream(device=dev) if world > 1 else None
     gathered_ev = [torch.cuda.Event() for _ in fgs]
+    assembled_ev = [torch.cuda.Event() for _ in fgs]
 
     def finish(k):
         # wait for the gather of the frame in buffer k, de-interleave and tone-map it on rank 0
@@ -372,7 +417,8 @@ def main():
             if frames_rgba[k] is not None:
                 staged[k] = fgs[k].final if not rehearsal else fgs[k].final.to(dev)
                 ctx.tonemap_device(staged[k].data_ptr(), frames_rgba[k].data_ptr(), H * W, side.cuda_stream)
-        stream.wait_event(gathered_ev[k])
+            assembled_ev[k].record(side)
+        stream.wait_event(gathered_ev[k])   # the strip buffer `local` of slot k may be rendered into again
 
     def step():
         k = frame_no[0] % len(fgs)
@@ -384,6 +430,9 @@ def main():
         if rehearsal:
             fgs[k].local.copy_(local)
         if world > 1:
+            # the next gather into slot k's `gathered` buffer must not start while the side stream
+            # still de-interleaves the previous frame out of it
+            stream.wait_event(assembled_ev[k])
             pending[k] = fgs[k].gather_async()  # RCCL gather of the packed strips to rank 0
 
     def drain():
@@ -583,12 +632,17 @@ def main():
             out["record_mode"] = {"pixels": int(args.record), "cap": 64, "segments": int(counts.sum()),
                                   "overflowed_pixels": int((counts > 64).sum()),
                                   "frame_plus_records_ms": (time.perf_counter() - t0) * 1e3}
+        if world > 1 and not rehearsal and not args.no_in_library_multi:
+            # every rank is idle here (rank 0 is past the last barrier of the timed work and the others
+            # wait in the barrier below), so the GPUs are free for the one-process form
+            out["in_library_multi"] = in_library_multi(world, args.workload, 20 if args.workload == "c2" else 3)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(scene, cam, prm)
             out["gpu_over_cpu_serial"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
     ctx.close()
     if world > 1:
+        dist.barrier()   # the other ranks stay idle until rank 0 has finished its extra measurements
         dist.destroy_process_group()
 
 
