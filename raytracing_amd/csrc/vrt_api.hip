@@ -102,6 +102,7 @@ extern "C" int vrt_set_option(vrt_ctx* c, const char* name, long long value)
     else if (n == "collapse_parity") o.collapse_parity = value != 0;
     else if (n == "no_big") o.no_big = value != 0;
     else if (n == "block_compact") o.block_compact = value != 0;
+    else if (n == "stack_cap") { if (value < 0 || value > VRT_TRAV_STACK) return fail(c, VRT_ERR_INVALID, "stack_cap: 0..VRT_TRAV_STACK"); o.stack_cap = (int)value; }
     else if (n == "quad_max") { if (value < -1 || value > 64) return fail(c, VRT_ERR_INVALID, "quad_max: -1..64"); o.quad_max = (int)value; }
     else if (n == "fail_after_build") o.fail_after_build = value != 0;
     else if (n == "packet") { if (value < -1 || value > 2) return fail(c, VRT_ERR_INVALID, "packet: -1, 0, 1 or 2"); o.packet = (int)value; }
@@ -450,6 +451,7 @@ static int build_scene(vrt_ctx* c, const vrt_scene_desc* d, SceneBufs& sb)
     S.lights = sb.d_lights;
     S.sh = d->shading;
     S.dbg = c->d_ctr;
+    S.stack_cap = VRT_TRAV_STACK;
     for (uint32_t i = 0; i < d->n_materials; ++i) {
         if (d->materials[i].type == VRT_MAT_MATTE) S.has_matte = 1;
         if (d->materials[i].type == VRT_MAT_TRANSPARENT) S.has_transparent = 1;
@@ -787,6 +789,7 @@ static int enqueue_frame(vrt_ctx* c, const vrt_params* p, const DevParams& P, fl
             ctr = c->d_ctr;
         }
         S.dbg = ctr; c->last_ctr = ctr;
+        S.stack_cap = c->opt.stack_cap > 0 ? c->opt.stack_cap : VRT_TRAV_STACK;
         HIPCHK(c, vrt_launch_wavefront(S, c->cam, P, c->sb.use_bvh, two, wf, rgba, hit, ctr, stream));
     } else {
         if (!ctr) {
@@ -805,6 +808,7 @@ static int enqueue_frame(vrt_ctx* c, const vrt_params* p, const DevParams& P, fl
             ctr = c->d_ctr_ring + (size_t)slot * kCtrBlock;
         }
         S.dbg = ctr; c->last_ctr = ctr;
+        S.stack_cap = c->opt.stack_cap > 0 ? c->opt.stack_cap : VRT_TRAV_STACK;
         if (c->sb.use_bvh && !two && !P.xcd_remap && c->opt.block_compact)
             HIPCHK(c, vrt_launch_mega_blk(S, c->cam, P, rgba, hit, ctr, stream));
         else
@@ -1183,6 +1187,7 @@ extern "C" int vrt_trace_pixel(vrt_ctx* c, const vrt_params* p, int h, int v, in
     int pix = h * c->cam.width + v, n = 0;
     HIPCHK(c, hipMemsetAsync(c->d_ctr, 0, VRT_CTR_SLOTS * VRT_CTR_STRIDE * sizeof(unsigned long long), c->stream));
     c->sb.scene.dbg = c->d_ctr; c->last_ctr = c->d_ctr;
+    c->sb.scene.stack_cap = c->opt.stack_cap > 0 ? c->opt.stack_cap : VRT_TRAV_STACK;
     rc = run_records(c, p, P, &pix, 1, cap, sample < 0 ? -1 : sample, segs, &n, c->d_px_rgba, c->d_px_hit, c->d_ctr);
     if (rc) return rc;
     float4 col; int id;
@@ -1208,6 +1213,7 @@ extern "C" int vrt_trace_ray(vrt_ctx* c, const vrt_params* p, const float origin
     HIPCHK(c, hipMemsetAsync(c->d_ctr, 0, VRT_CTR_SLOTS * VRT_CTR_STRIDE * sizeof(unsigned long long), c->stream));
     const bool two = two_children(c, p);
     c->sb.scene.dbg = c->d_ctr; c->last_ctr = c->d_ctr;
+    c->sb.scene.stack_cap = c->opt.stack_cap > 0 ? c->opt.stack_cap : VRT_TRAV_STACK;
     HIPCHK(c, vrt_launch_ray(c->sb.scene, P, c->sb.use_bvh, two, origin, direction, depth, c->d_px_rgba, c->d_px_hit,
                              c->d_ctr, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -25,6 +25,13 @@
 
 #define VRT_MAX_BIG 8
 
+// Traversal-stack entries per lane (LDS, 8 bytes each): 16 entries x 64 lanes = 8 KiB per one-wave
+// block, so 16 such blocks fit a CU beside their counters.  Measured on MI355X: 12 entries cost the
+// 1M-triangle frame 12 % (stackless finishes), 24 entries cost both tree workloads 20 % (occupancy).
+#ifndef VRT_TRAV_STACK
+#define VRT_TRAV_STACK 16
+#endif
+
 struct DevLight {
     int type;
     float vx, vy, vz;
@@ -60,6 +67,7 @@ struct DevScene {
     int n_big;
     int big[VRT_MAX_BIG];
     unsigned long long* dbg; // the context's counter block (slots 6, 7: nodes entered, primitives tested)
+    int stack_cap;           // traversal-stack entries per lane in use: VRT_TRAV_STACK (vrt_trace.h) unless a test shortens it
     int has_matte, has_transparent; // some material is of class VRT_MAT_MATTE / VRT_MAT_TRANSPARENT
     vrt_shading sh;
 };

@@ -315,9 +315,6 @@ __device__ __forceinline__ bool slab_test(f3 lo, f3 hi, f3 o, f3 inv, float tmax
 #ifndef VRT_STACK_LANES
 #define VRT_STACK_LANES 64
 #endif
-#ifndef VRT_TRAV_STACK
-#define VRT_TRAV_STACK 16
-#endif
 __shared__ unsigned long long g_lds_stack[VRT_TRAV_STACK * VRT_STACK_LANES];
 
 // Orders two (tnear, code) candidates, nearer first.
@@ -394,9 +391,9 @@ __device__ __forceinline__ Slab4 slab4(float4 lx, float4 ly, float4 lz, float4 h
     return r;
 }
 
-__device__ __forceinline__ void trav_push(Trav& T, unsigned long long* my_lds, float tnear, int code)
+__device__ __forceinline__ void trav_push(const DevScene& S, Trav& T, unsigned long long* my_lds, float tnear, int code)
 {
-    if (T.sp < VRT_TRAV_STACK) {
+    if (T.sp < S.stack_cap) {   // VRT_TRAV_STACK unless a test shortens it
         my_lds[T.sp * VRT_STACK_LANES] = ((unsigned long long)__float_as_uint(tnear) << 32) | (unsigned)code;
         T.sp++;
     } else {
@@ -417,7 +414,7 @@ __device__ __forceinline__ bool trav_inner(const DevScene& S, Trav& T, unsigned 
     Slab4 r = slab4(lx, ly, lz, hx, hy, hz, T.o, T.inv, trav_limit(T));
     if (any) {
         bool taken = false;
-#define VRT_VISIT_ANY(H, C) if (H) { if (!taken) { T.node = C; taken = true; } else trav_push(T, my_lds, 0.f, C); }
+#define VRT_VISIT_ANY(H, C) if (H) { if (!taken) { T.node = C; taken = true; } else trav_push(S, T, my_lds, 0.f, C); }
         VRT_VISIT_ANY(r.h0, c0) VRT_VISIT_ANY(r.h1, c1) VRT_VISIT_ANY(r.h2, c2) VRT_VISIT_ANY(r.h3, c3)
 #undef VRT_VISIT_ANY
         return !taken;
@@ -428,9 +425,9 @@ __device__ __forceinline__ bool trav_inner(const DevScene& S, Trav& T, unsigned 
     order2(t1, c1, t2, c2);
     if (!(t0 < INFINITY)) return true;
     T.node = c0;
-    if (t3 < INFINITY) trav_push(T, my_lds, t3, c3);
-    if (t2 < INFINITY) trav_push(T, my_lds, t2, c2);
-    if (t1 < INFINITY) trav_push(T, my_lds, t1, c1);
+    if (t3 < INFINITY) trav_push(S, T, my_lds, t3, c3);
+    if (t2 < INFINITY) trav_push(S, T, my_lds, t2, c2);
+    if (t1 < INFINITY) trav_push(S, T, my_lds, t1, c1);
     return false;
 }
 
@@ -583,7 +580,7 @@ __device__ __forceinline__ bool intersect_bvh4_packet(const DevScene& S, Trav& T
             if (kmin != 0x7fffffff) {
                 pop = false;
                 const int n_push = (m0 != 0) + (m1 != 0) + (m2 != 0) + (m3 != 0) - 1;
-                if (sp + n_push > VRT_TRAV_STACK) return false;
+                if (sp + n_push > S.stack_cap) return false;
 #define VRT_PPUSH(I, M, H, TT, C)                                                                           \
                 if (first != I && M) {                                                                      \
                     my_lds[sp * VRT_STACK_LANES] =                                                          \
@@ -696,10 +693,10 @@ __device__ __forceinline__ bool quad_inner(const DevScene& S, Trav& T, int c, in
     const int n_push = n_hit - 1;
     if (hit && rank >= 1) {
         const int e = T.sp + (n_push - rank);
-        if (e < 4 * VRT_TRAV_STACK) *quad_slot(qcol, e) = ((unsigned long long)__float_as_uint(t0) << 32) | (unsigned)code;
+        if (e < 4 * S.stack_cap) *quad_slot(qcol, e) = ((unsigned long long)__float_as_uint(t0) << 32) | (unsigned)code;
     }
     T.sp += n_push;
-    if (T.sp > 4 * VRT_TRAV_STACK) { T.sp = 4 * VRT_TRAV_STACK; T.ovf = true; }   // finished by trav_stackless()
+    if (T.sp > 4 * S.stack_cap) { T.sp = 4 * S.stack_cap; T.ovf = true; }   // finished by trav_stackless()
     T.node = (int)next;
     return false;
 }

@@ -208,3 +208,32 @@ def test_block_compaction_is_bitwise_invisible(vrt_ctx, vrt_opts, which, spp):
     vrt_ctx.render(ra.Params(spp=spp, offsets=offs, seed=5, max_depth=7, rng=rng, flags=flags, tile_index=2, tile_count=3,
                              tile_rows=8, compact_rows=True), rgba=out, hit=np.zeros((len(rows), 131), np.int32))
     assert np.array_equal(out, b[rows], equal_nan=True)
+
+
+@pytest.mark.parametrize("which", ["spheres", "mesh"])
+@pytest.mark.parametrize("cap", [1, 3, 7])
+def test_stackless_finish_gives_the_same_frame(vrt_ctx, vrt_opts, which, cap):
+    """The traversal stack lives in LDS and is short; a query that outgrows it is finished by a
+    stackless walk of the binary tree.  With the stack cut to 1, 3 or 7 entries most queries take
+    that route (per-lane, wave-uniform and four-lanes-per-ray traversals alike), and frames, hit ids,
+    ray counts and recorded ray trees must be those of the full stack, in both kernel organisations."""
+    if which == "spheres":
+        scene, cam, rng = ra.random_spheres_scene(n=1500, seed=3), ra.random_spheres_camera(120, 68), 200.0
+    else:
+        scene, cam, rng = ra.tessellated_mesh_scene(quads=40), ra.tessellated_mesh_camera(120, 68), 100.0
+    offs = host.sampler_table(abi.VRT_SAMPLER_JITTERED, 4, 3, 0.02, 0.02, seed=5)
+    kw = dict(spp=4, offsets=offs, seed=2, max_depth=5, rng=rng)
+    vrt_ctx.set_scene(scene)
+    vrt_ctx.set_camera(cam)
+    ref, ref_hit, ref_st = vrt_ctx.render(ra.Params(**kw))
+    ref_px = vrt_ctx.trace_pixel(ra.Params(**kw), 30, 60, -1, 128)
+    vrt_opts("stack_cap", cap)
+    for mode in (abi.VRT_MODE_MEGAKERNEL, abi.VRT_MODE_WAVEFRONT):
+        for packet in (0, 1):
+            vrt_opts("packet", packet)
+            got, got_hit, st = vrt_ctx.render(ra.Params(mode=mode, **kw))
+            assert np.array_equal(got, ref, equal_nan=True) and np.array_equal(got_hit, ref_hit)
+            assert list(st.rays) == list(ref_st.rays)
+    px = vrt_ctx.trace_pixel(ra.Params(**kw), 30, 60, -1, 128)   # state machine, four lanes per ray
+    assert px[3] == ref_px[3] and bytes(px[2])[:px[3] * 40] == bytes(ref_px[2])[:px[3] * 40]
+    assert np.array_equal(px[0], ref_px[0], equal_nan=True)
