@@ -956,10 +956,12 @@ __device__ __forceinline__ f3 ambient_L(const DevScene& S, const DevParams& P, f
 
 // Material/PhongMaterial.cs:53-89 with BRDF/LambertianBRDF.cs:23-26,54-57,
 // BRDF/GlossySpecularBRDF.cs:40-63, Light/PointLight.cs:23-51, Light/DirectionalLight.cs:22-42.
+// matte: Material/MatteMaterial.cs:44-75 instead: the same ambient term, no shadow test, no specular
+// lobe, and the light term associated as (F * L) * ndotwi.
 template <bool BVH, bool RECORD, class OCC>
 __device__ __forceinline__ f3 phong_shade(const DevScene& S, const DevParams& P, f3 point, f3 n, int prim,
                                           f3 raydir, int depth, float ka, float kd, float ks, float ex,
-                                          f3 cd, Counters& C, Recorder& R, OCC& occ)
+                                          f3 cd, Counters& C, Recorder& R, OCC& occ, bool matte = false)
 {
     f3 wo = -raydir;
     f3 L = (cd * ka) * ambient_L<BVH, RECORD>(S, P, point, n, prim, depth, C, R, occ);
@@ -977,7 +979,7 @@ __device__ __forceinline__ f3 phong_shade(const DevScene& S, const DevParams& P,
         float ndotwi = dot3(n, wi);
         if (ndotwi > 0.f) {
             bool in_shadow = false;
-            if (l.cast) {
+            if (l.cast && !matte) {
                 f3 sd = normalize3(wi);
                 f3 loc = l.type == VRT_LIGHT_POINT ? lp : mk3(l.lx, l.ly, l.lz);
                 float dist = mag3(loc - point);
@@ -994,7 +996,10 @@ __device__ __forceinline__ f3 phong_shade(const DevScene& S, const DevParams& P,
                     }
                 }
             }
-            if (!in_shadow) {
+            if (matte) {
+                f3 f = (cd * kd) * 0.3183098861837906715f;
+                L = L + (f * (mk3(l.cr, l.cg, l.cb) * l.ls)) * ndotwi;
+            } else if (!in_shadow) {
                 f3 diff = (cd * kd) * 0.3183098861837906715f;
                 float spec = 0.f;
                 // ks = 0 (the solid material) makes the lobe 0 * pow = 0 for every finite pow,
@@ -1009,33 +1014,6 @@ __device__ __forceinline__ f3 phong_shade(const DevScene& S, const DevParams& P,
                 f3 world = (mk3(l.cr, l.cg, l.cb) * l.ls) * ndotwi;
                 L = L + lam * world;
             }
-        }
-    }
-    return L;
-}
-
-// Material/MatteMaterial.cs:44-75: ambient term and one Lambert term per light that faces the
-// surface; no shadow test, no specular lobe.  The light term is F * L * ndotwi, left to right.
-template <bool BVH, bool RECORD, class OCC>
-__device__ __forceinline__ f3 matte_shade(const DevScene& S, const DevParams& P, f3 point, f3 n, int prim, int depth,
-                                          f3 cd, Counters& C, Recorder& R, OCC& occ)
-{
-    f3 L = (cd * S.sh.matte_ka) * ambient_L<BVH, RECORD>(S, P, point, n, prim, depth, C, R, occ);
-    for (int i = 0; i < S.n_lights; ++i) {
-        const DevLight& l = S.lights[i];
-        f3 lp = mk3(l.vx, l.vy, l.vz);
-        f3 wi;
-        if (l.type == VRT_LIGHT_POINT) {
-            f3 tmp = lp - point;
-            float len = sqrtf(tmp.x * tmp.x + tmp.y * tmp.y + tmp.z * tmp.z);
-            wi = mk3(tmp.x / len, tmp.y / len, tmp.z / len);
-        } else {
-            wi = lp;
-        }
-        float ndotwi = dot3(n, wi);
-        if (ndotwi > 0.f) {
-            f3 f = (cd * S.sh.matte_kd) * 0.3183098861837906715f;
-            L = L + (f * (mk3(l.cr, l.cg, l.cb) * l.ls)) * ndotwi;
         }
     }
     return L;
@@ -1156,19 +1134,26 @@ __device__ __forceinline__ void shade_hit(const DevScene& S, const DevParams& P,
     f3 cd = mk3(m.x, m.y, m.z);
     const vrt_shading& sh = S.sh;
     int n_child = 0;
-    f3 A = mk3(0.f, 0.f, 0.f), d0 = A, w0 = A, d1 = A, w1 = A;
-    if (mtype == VRT_MAT_METAL) {
-        A = phong_shade<BVH, RECORD>(S, P, point, n, h.prim, d, depth, sh.metal_ka, sh.metal_kd,
-                                       sh.metal_ks, sh.metal_exp, cd, C, R, occ);
+    f3 d0 = mk3(0.f, 0.f, 0.f), w0 = d0, d1 = d0, w1 = d0;
+    // One Phong site for every material class: the lanes of a wave shade hits on different
+    // materials, and with a call per class their ambient-occlusion and shadow traversals would run
+    // one class after the other with a part of the lanes each.
+    const bool metal = mtype == VRT_MAT_METAL, glass = mtype == VRT_MAT_DIELECTRIC;
+    const bool matte = P.general && mtype == VRT_MAT_MATTE, transp = P.general && mtype == VRT_MAT_TRANSPARENT;
+    float ka = sh.solid_ka, kd = sh.solid_kd, ks = sh.solid_ks, ex = sh.solid_exp;
+    if (metal) { ka = sh.metal_ka; kd = sh.metal_kd; ks = sh.metal_ks; ex = sh.metal_exp; }
+    if (glass) { ka = sh.glass_ka; kd = sh.glass_kd; ks = sh.glass_ks; ex = sh.glass_exp; }
+    if (matte) { ka = sh.matte_ka; kd = sh.matte_kd; ks = 0.f; ex = 1.f; }
+    if (transp) { ka = sh.transp_ka; kd = sh.transp_kd; ks = sh.transp_ks; ex = sh.transp_exp; }
+    const f3 A = phong_shade<BVH, RECORD>(S, P, point, n, h.prim, d, depth, ka, kd, ks, ex, cd, C, R, occ, matte);
+    if (metal) {
         f3 wo = -d;
         float ndotwo = dot3(n, wo);
         f3 wi = (-wo) + (n * 2.f) * ndotwo;
         float nd = dot3(n, wi);
         f3 fr = (mk3(sh.metal_cr[0], sh.metal_cr[1], sh.metal_cr[2]) * sh.metal_kr) / fabsf(nd);
         n_child = 1; d0 = normalize3(wi); w0 = fr * nd;
-    } else if (mtype == VRT_MAT_DIELECTRIC) {
-        A = phong_shade<BVH, RECORD>(S, P, point, n, h.prim, d, depth, sh.glass_ka, sh.glass_kd,
-                                       sh.glass_ks, sh.glass_exp, cd, C, R, occ);
+    } else if (glass) {
         f3 wo = -d;
         float ndotwo = dot3(n, wo);
         f3 wi = (-wo) + (n * 2.f) * ndotwo;
@@ -1191,15 +1176,8 @@ __device__ __forceinline__ void shade_hit(const DevScene& S, const DevParams& P,
                 n_child = 2; d1 = normalize3(wt); w1 = mk3(wtt, wtt, wtt);
             }
         }
-    } else if (P.general && mtype == VRT_MAT_MATTE) {
-        A = matte_shade<BVH, RECORD>(S, P, point, n, h.prim, depth, cd, C, R, occ);
-    } else if (P.general && mtype == VRT_MAT_TRANSPARENT) {
-        A = phong_shade<BVH, RECORD>(S, P, point, n, h.prim, d, depth, sh.transp_ka, sh.transp_kd,
-                                       sh.transp_ks, sh.transp_exp, cd, C, R, occ);
+    } else if (transp) {
         n_child = transparent_children(sh, n, d, d0, w0, d1, w1);
-    } else {
-        A = phong_shade<BVH, RECORD>(S, P, point, n, h.prim, d, depth, sh.solid_ka, sh.solid_kd,
-                                       sh.solid_ks, sh.solid_exp, cd, C, R, occ);
     }
     B.prim = h.prim; B.o = point; B.n_child = n_child; B.A = A; B.d0 = d0; B.w0 = w0; B.d1 = d1; B.w1 = w1;
 }
