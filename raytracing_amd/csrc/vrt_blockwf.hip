@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256, 4) void k_mega_blk(DevScene S, DevCam cam, Dev
     const int h = local_to_global_row(P, r);
     Counters C = {0, 0, 0, 0, 0, 0};
     if (tid < VRT_RAY_CLASSES) g_lds_ctr[tid] = 0;
-    __syncthreads();
+    stage_materials(S);
     Recorder R; R.segs = nullptr; R.cap = 0; R.n = 0; R.sample = 0;
     const bool inside = tile < n_tiles && v < cam.width && r < P.local_rows && h < cam.height;
     const f3 O = mk3(cam.ox, cam.oy, cam.oz);

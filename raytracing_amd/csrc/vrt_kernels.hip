@@ -60,6 +60,7 @@ __global__ __launch_bounds__(VRT_MEGA_THREADS, BVH ? VRT_BVH_WAVES : (SIMPLE ? V
     const int r = (by << (pshift - pw_shift)) + (pi >> pw_shift);
     const int h = local_to_global_row(P, r);
     if (!BVH) stage_prims(S);
+    stage_materials(S);
     Counters C = {0, 0, 0, 0, 0, 0};
 #if VRT_LDS_COUNTERS
     if (threadIdx.x < VRT_RAY_CLASSES) g_lds_ctr[threadIdx.x] = 0;
@@ -138,6 +139,7 @@ __global__ __launch_bounds__(64) void k_pixels(DevScene S, DevCam cam, DevParams
     int i = blockIdx.x * 64 + threadIdx.x;
     if (!TWOCHILD) P.general = 0;
     if (!BVH) stage_prims(S);
+    stage_materials(S);
     Counters C = {0, 0, 0, 0, 0, 0};
 #if VRT_LDS_COUNTERS
     if (threadIdx.x < VRT_RAY_CLASSES) g_lds_ctr[threadIdx.x] = 0;
@@ -173,6 +175,7 @@ __global__ __launch_bounds__(64) void k_ray(DevScene S, DevParams P, float ox, f
 {
     if (!TWOCHILD) P.general = 0;
     if (!BVH) stage_prims(S);
+    stage_materials(S);
     Counters C = {0, 0, 0, 0, 0, 0};
 #if VRT_LDS_COUNTERS
     if (threadIdx.x < VRT_RAY_CLASSES) g_lds_ctr[threadIdx.x] = 0;

@@ -890,6 +890,25 @@ __device__ __forceinline__ void record_seg(Recorder& R, f3 o, f3 d, Hit h, int k
 
 // ------------------------------------------------------------------ shading
 
+// Phong coefficients (ka, kd, ks, exp) by material class (VRT_MAT_*), one copy per block in LDS.
+// The whole block calls stage_materials() once before it shades anything.
+__shared__ float4 g_lds_matk[8];
+__device__ __forceinline__ void stage_materials(const DevScene& S)
+{
+    if (threadIdx.x == 0) {
+        const vrt_shading& sh = S.sh;
+        const float4 solid = make_float4(sh.solid_ka, sh.solid_kd, sh.solid_ks, sh.solid_exp);
+        g_lds_matk[0] = solid;
+        g_lds_matk[VRT_MAT_SOLID] = solid;
+        g_lds_matk[VRT_MAT_METAL] = make_float4(sh.metal_ka, sh.metal_kd, sh.metal_ks, sh.metal_exp);
+        g_lds_matk[VRT_MAT_DIELECTRIC] = make_float4(sh.glass_ka, sh.glass_kd, sh.glass_ks, sh.glass_exp);
+        g_lds_matk[VRT_MAT_MATTE] = make_float4(sh.matte_ka, sh.matte_kd, 0.f, 1.f);
+        g_lds_matk[VRT_MAT_TRANSPARENT] = make_float4(sh.transp_ka, sh.transp_kd, sh.transp_ks, sh.transp_exp);
+        g_lds_matk[6] = solid; g_lds_matk[7] = solid;
+    }
+    __syncthreads();
+}
+
 // Util/RayTraceUtility.cs:123-131
 __device__ __forceinline__ f3 sky_color(f3 direction)
 {
@@ -1140,12 +1159,10 @@ __device__ __forceinline__ void shade_hit(const DevScene& S, const DevParams& P,
     // one class after the other with a part of the lanes each.
     const bool metal = mtype == VRT_MAT_METAL, glass = mtype == VRT_MAT_DIELECTRIC;
     const bool matte = P.general && mtype == VRT_MAT_MATTE, transp = P.general && mtype == VRT_MAT_TRANSPARENT;
-    float ka = sh.solid_ka, kd = sh.solid_kd, ks = sh.solid_ks, ex = sh.solid_exp;
-    if (metal) { ka = sh.metal_ka; kd = sh.metal_kd; ks = sh.metal_ks; ex = sh.metal_exp; }
-    if (glass) { ka = sh.glass_ka; kd = sh.glass_kd; ks = sh.glass_ks; ex = sh.glass_exp; }
-    if (matte) { ka = sh.matte_ka; kd = sh.matte_kd; ks = 0.f; ex = 1.f; }
-    if (transp) { ka = sh.transp_ka; kd = sh.transp_kd; ks = sh.transp_ks; ex = sh.transp_exp; }
-    const f3 A = phong_shade<BVH, RECORD>(S, P, point, n, h.prim, d, depth, ka, kd, ks, ex, cd, C, R, occ, matte);
+    // (ka, kd, ks, exp) of the hit's class from the block's table in LDS (stage_materials): the class
+    // differs per lane, and a chain of selects over kernel arguments ends up as a table in scratch
+    const float4 k = g_lds_matk[(matte || transp || metal || glass) ? (mtype & 7) : VRT_MAT_SOLID];
+    const f3 A = phong_shade<BVH, RECORD>(S, P, point, n, h.prim, d, depth, k.x, k.y, k.z, k.w, cd, C, R, occ, matte);
     if (metal) {
         f3 wo = -d;
         float ndotwo = dot3(n, wo);

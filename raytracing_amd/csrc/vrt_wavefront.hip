@@ -199,6 +199,7 @@ __global__ __launch_bounds__(256, 4) void k_wf_primary(DevScene S, DevCam cam, D
     const int h = local_to_global_row(P, r);
     const bool inside = tile < n_tiles && v < cam.width && rb < band_rows && r < P.local_rows && h < cam.height;
     if (!BVH) stage_prims(S);
+    stage_materials(S);
     Counters C = {0, 0, 0, 0, 0, 0};
 #if VRT_LDS_COUNTERS
     if (threadIdx.x < VRT_RAY_CLASSES) g_lds_ctr[threadIdx.x] = 0;
@@ -247,6 +248,7 @@ __global__ __launch_bounds__(256, VRT_WF_BOUNCE_BLOCKS) void k_wf_bounce(DevScen
     int count = W.counts[depth - 1];
     if (count > (int)W.cap) count = (int)W.cap;
     if (!BVH) stage_prims(S);
+    stage_materials(S);
     Counters C = {0, 0, 0, 0, 0, 0};
 #if VRT_LDS_COUNTERS
     if (threadIdx.x < VRT_RAY_CLASSES) g_lds_ctr[threadIdx.x] = 0;
@@ -293,6 +295,7 @@ __global__ __launch_bounds__(256, VRT_WF_BOUNCE_BLOCKS) void k_wf_bounce_a(DevSc
     int count = W.counts[depth - 1];
     if (count > (int)W.cap) count = (int)W.cap;
     if (!BVH) stage_prims(S);
+    stage_materials(S);
     Counters C = {0, 0, 0, 0, 0, 0};
 #if VRT_LDS_COUNTERS
     if (threadIdx.x < VRT_RAY_CLASSES) g_lds_ctr[threadIdx.x] = 0;
@@ -336,6 +339,7 @@ __global__ __launch_bounds__(256, VRT_WF_BOUNCE_BLOCKS) void k_wf_any(DevScene S
     int count = W.any_counts[depth];
     if (count > (int)W.any_cap) count = (int)W.any_cap;
     if (!BVH) stage_prims(S);
+    stage_materials(S);
     const AnyQueue& q = W.any;
     const int stride = gridDim.x * 256;
     for (int j = blockIdx.x * 256 + threadIdx.x; j < count; j += stride) {
@@ -475,6 +479,7 @@ __global__ __launch_bounds__(256, VRT_WF_BOUNCE_BLOCKS) void k_wf_bounce_b(DevSc
     int count = W.counts[depth - 1];
     if (count > (int)W.cap) count = (int)W.cap;
     Counters C = {0, 0, 0, 0, 0, 0};   // rays were counted in pass a
+    stage_materials(S);
     __shared__ int s_chunk[4][4];
     volatile int* st = chunk_state_init(s_chunk);
     const int stride = gridDim.x * 256;
