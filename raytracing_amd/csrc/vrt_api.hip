@@ -83,6 +83,7 @@ static void options_from_env(VrtOptions& o)
     o.packet = (int)geti("VRT_PACKET", -1);
     o.block_compact = (int)geti("VRT_BLOCK_COMPACT", 0);
     o.quad_max = (int)geti("VRT_QUAD_MAX", -1);
+    o.slab_fma = (int)geti("VRT_SLAB_FMA", 1);
 }
 
 extern "C" int vrt_set_option(vrt_ctx* c, const char* name, long long value)
@@ -102,6 +103,7 @@ extern "C" int vrt_set_option(vrt_ctx* c, const char* name, long long value)
     else if (n == "collapse_parity") o.collapse_parity = value != 0;
     else if (n == "no_big") o.no_big = value != 0;
     else if (n == "block_compact") o.block_compact = value != 0;
+    else if (n == "slab_fma") o.slab_fma = value != 0;
     else if (n == "stack_cap") { if (value < 0 || value > VRT_TRAV_STACK) return fail(c, VRT_ERR_INVALID, "stack_cap: 0..VRT_TRAV_STACK"); o.stack_cap = (int)value; }
     else if (n == "quad_max") { if (value < -1 || value > 64) return fail(c, VRT_ERR_INVALID, "quad_max: -1..64"); o.quad_max = (int)value; }
     else if (n == "fail_after_build") o.fail_after_build = value != 0;
@@ -491,6 +493,8 @@ static int build_scene(vrt_ctx* c, const vrt_scene_desc* d, SceneBufs& sb)
         }
         double scene_ext = 0;
         for (int k = 0; k < 3; ++k) if (hi[k] - lo[k] > scene_ext) scene_ext = hi[k] - lo[k];
+        sb.max_abs = 0;
+        for (int k = 0; k < 3; ++k) sb.max_abs = std::max(sb.max_abs, std::max(fabs(lo[k]), fabs(hi[k])));
         std::sort(ext.begin(), ext.end(), [](const std::pair<double, int>& a, const std::pair<double, int>& b) {
             return a.first > b.first || (a.first == b.first && a.second < b.second);
         });
@@ -525,6 +529,21 @@ static int build_scene(vrt_ctx* c, const vrt_scene_desc* d, SceneBufs& sb)
     }
     return refresh_cam_pre(c, sb);
 }
+
+// Whether this frame's box tests may take the fused form (slab4 in vrt_trace.h): every ray starts
+// at the camera (or at `origin`) or on a surface of the scene, and the fused form is proven to keep
+// every candidate only while those points lie within +-1600 of the coordinate origin.
+static bool fused_form(const vrt_ctx* c, const float* origin)
+{
+    if (!c->sb.use_bvh || c->opt.slab_fma == 0) return false;
+    double m = c->sb.max_abs;
+    const float cam[3] = {c->cam.ox, c->cam.oy, c->cam.oz};
+    const float* o = origin ? origin : cam;
+    for (int k = 0; k < 3; ++k) m = std::max(m, (double)fabsf(o[k]));
+    return m <= 1600.0;
+}
+
+#define VRT_LAUNCH(fused, fn, ...) ((fused) ? vrt_fused::fn(__VA_ARGS__) : vrt_plain::fn(__VA_ARGS__))
 
 // Assembles the scene beside the current one on this context's GPU (vrt_swap_scene_one makes it
 // current).  On failure `nb` is released and the context still renders the scene it had.
@@ -790,7 +809,7 @@ static int enqueue_frame(vrt_ctx* c, const vrt_params* p, const DevParams& P, fl
         }
         S.dbg = ctr; c->last_ctr = ctr;
         S.stack_cap = c->opt.stack_cap > 0 ? c->opt.stack_cap : VRT_TRAV_STACK;
-        HIPCHK(c, vrt_launch_wavefront(S, c->cam, P, c->sb.use_bvh, two, wf, rgba, hit, ctr, stream));
+        HIPCHK(c, VRT_LAUNCH(fused_form(c, nullptr), vrt_launch_wavefront, S, c->cam, P, c->sb.use_bvh, two, wf, rgba, hit, ctr, stream));
     } else {
         if (!ctr) {
             // Blocks of the ring are clean when their turn comes only if the frames of a round ran
@@ -809,10 +828,11 @@ static int enqueue_frame(vrt_ctx* c, const vrt_params* p, const DevParams& P, fl
         }
         S.dbg = ctr; c->last_ctr = ctr;
         S.stack_cap = c->opt.stack_cap > 0 ? c->opt.stack_cap : VRT_TRAV_STACK;
+        const bool fused = fused_form(c, nullptr);
         if (c->sb.use_bvh && !two && !P.xcd_remap && c->opt.block_compact)
-            HIPCHK(c, vrt_launch_mega_blk(S, c->cam, P, rgba, hit, ctr, stream));
+            HIPCHK(c, VRT_LAUNCH(fused, vrt_launch_mega_blk, S, c->cam, P, rgba, hit, ctr, stream));
         else
-            HIPCHK(c, vrt_launch_mega(S, c->cam, P, c->sb.use_bvh, two, rgba, hit, ctr, stream));
+            HIPCHK(c, VRT_LAUNCH(fused, vrt_launch_mega, S, c->cam, P, c->sb.use_bvh, two, rgba, hit, ctr, stream));
     }
     c->last_pixels = (uint64_t)P.local_rows * c->cam.width;
     c->last_mode = mode;
@@ -882,7 +902,7 @@ static int run_records(vrt_ctx* c, const vrt_params* p, const DevParams& P, cons
     }
     HIPCHK(c, hipMemcpyAsync(c->d_rec_pixels, pixels, n * sizeof(int), hipMemcpyHostToDevice, c->stream));
     const bool two = two_children(c, p);
-    HIPCHK(c, vrt_launch_pixels(c->sb.scene, c->cam, P, c->sb.use_bvh, two, c->d_rec_pixels, n, sample_sel, c->d_segs,
+    HIPCHK(c, VRT_LAUNCH(fused_form(c, nullptr), vrt_launch_pixels, c->sb.scene, c->cam, P, c->sb.use_bvh, two, c->d_rec_pixels, n, sample_sel, c->d_segs,
                                 cap, c->d_seg_counts, rgba_dev, hit_dev, ctr, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (counts_out) HIPCHK(c, hipMemcpy(counts_out, c->d_seg_counts, n * sizeof(int), hipMemcpyDeviceToHost));
@@ -1214,7 +1234,7 @@ extern "C" int vrt_trace_ray(vrt_ctx* c, const vrt_params* p, const float origin
     const bool two = two_children(c, p);
     c->sb.scene.dbg = c->d_ctr; c->last_ctr = c->d_ctr;
     c->sb.scene.stack_cap = c->opt.stack_cap > 0 ? c->opt.stack_cap : VRT_TRAV_STACK;
-    HIPCHK(c, vrt_launch_ray(c->sb.scene, P, c->sb.use_bvh, two, origin, direction, depth, c->d_px_rgba, c->d_px_hit,
+    HIPCHK(c, VRT_LAUNCH(fused_form(c, origin), vrt_launch_ray, c->sb.scene, P, c->sb.use_bvh, two, origin, direction, depth, c->d_px_rgba, c->d_px_hit,
                              c->d_ctr, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     float4 col; int id;

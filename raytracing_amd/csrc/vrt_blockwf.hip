@@ -19,6 +19,7 @@
 #include "vrt_trace.h"
 #include "vrt_launch.h"
 
+namespace VRT_FORM {
 namespace {
 
 __shared__ float s_lacc[3][256];              // radiance of the block's samples by owner lane
@@ -194,3 +195,5 @@ hipError_t vrt_launch_mega_blk(const DevScene& S, const DevCam& cam, const DevPa
         hipLaunchKernelGGL((k_mega_blk<true>), grid, block, 0, stream, S, cam, P, rgba, hit_id, ctr, blocks_x, n_tiles);
     return hipGetLastError();
 }
+
+} // namespace VRT_FORM

@@ -10,7 +10,7 @@
 
 // Study and test knobs.  Environment variables of the same meaning (VRT_XCD_REMAP, VRT_SAMPLE_SHIFT,
 // VRT_WF_DEFER, VRT_WF_REFILL, VRT_WF_MAX_SLOTS, VRT_WF_ANY_CAP, VRT_BUILDER, VRT_COLLAPSE_PARITY,
-// VRT_NO_BIG, VRT_PACKET, VRT_BLOCK_COMPACT) are read once, when the context is created; vrt_set_option changes
+// VRT_NO_BIG, VRT_PACKET, VRT_BLOCK_COMPACT, VRT_SLAB_FMA) are read once, when the context is created; vrt_set_option changes
 // them afterwards.  Nothing on the per-frame path reads the environment.
 struct VrtOptions {
     int xcd_remap = 0;          // 1: each XCD renders one contiguous band of tiles (measured slower)
@@ -25,6 +25,7 @@ struct VrtOptions {
     int no_big = 0;             // 1: scene-sized primitives stay in the tree
     int packet = -1;            // tree scenes: wave-uniform traversal for the rays of one pixel group; -1 = chosen from spp
     int quad_max = -1;          // tree scenes: waves with at most this many queries trace them four lanes per ray; -1 = library default
+    int slab_fma = 1;           // tree scenes: fused box test where the scene lies near enough to the origin for it (0: never)
     int stack_cap = 0;          // tests: traversal-stack entries per lane (0 = all the kernels have), forces the stackless finish
     int block_compact = 0;      // tree scenes, one child per hit: bounces compacted inside four-wave blocks (0: one wave per tile through all bounces)
     int fail_after_build = 0;   // tests: vrt_set_scene reports a failure after uploads and tree build have succeeded
@@ -43,6 +44,7 @@ struct SceneBufs {
     bool use_bvh = false;
     float bvh_ms = 0.f;
     int bvh_depth = 0;
+    double max_abs = 0;   // tree scenes: largest |coordinate| of the scene's bounds
     void release();
 };
 

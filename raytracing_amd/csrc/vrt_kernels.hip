@@ -22,6 +22,8 @@
 // brute-force variants fit 106-124 registers; 5 waves gain 1 % and add scratch traffic.
 // P.xcd_remap (off by default, see vrt_api.hip) renumbers blocks so that the 8 blocks dealt
 // round-robin to the 8 XCDs come from 8 separate bands of the image.
+namespace VRT_FORM {
+
 #define VRT_MEGA_THREADS 64
 #ifndef VRT_BVH_WAVES
 #define VRT_BVH_WAVES 4
@@ -214,13 +216,19 @@ hipError_t vrt_launch_mega(const DevScene& S, const DevCam& cam, const DevParams
     int n_blocks = blocks_x * blocks_y;
     if (n_blocks <= 0) return hipSuccess;
     dim3 grid(n_blocks), block(VRT_MEGA_THREADS);
+#if !VRT_SLAB_FMA
     const bool simple = !bvh && S.n_tri == 0 && S.all_aab && !S.mat_tex && !S.has_matte && !S.has_transparent;
+#endif
 #define VRT_GO3(B, T, SP, SI) hipLaunchKernelGGL((k_mega<B, T, SP, SI>), grid, block, 0, stream, S, cam, P, rgba, hit_id, ctr, blocks_x, n_blocks)
 #define VRT_GO(B, T) do { if (shift == 0) VRT_GO3(B, T, false, false); else VRT_GO3(B, T, true, false); } while (0)
 #define VRT_GOS(T) do { if (shift == 0) VRT_GO3(false, T, false, true); else VRT_GO3(false, T, true, true); } while (0)
     if (bvh) { if (twochild) VRT_GO(true, true); else VRT_GO(true, false); }
+#if VRT_SLAB_FMA
+    else return hipErrorInvalidValue;   // the fused form only differs where a tree is walked
+#else
     else if (simple) { if (twochild) VRT_GOS(true); else VRT_GOS(false); }
     else     { if (twochild) VRT_GO(false, true); else VRT_GO(false, false); }
+#endif
 #undef VRT_GOS
 #undef VRT_GO3
 #undef VRT_GO
@@ -236,7 +244,11 @@ hipError_t vrt_launch_pixels(const DevScene& S, const DevCam& cam, const DevPara
     dim3 grid(div_up(n_pixels, 64)), block(64);
 #define VRT_GO(B, T) hipLaunchKernelGGL((k_pixels<B, T>), grid, block, 0, stream, S, cam, P, pixels, n_pixels, sample_sel, segs, cap, seg_counts, rgba_out, hit_out, ctr)
     if (bvh) { if (twochild) VRT_GO(true, true); else VRT_GO(true, false); }
+#if VRT_SLAB_FMA
+    else return hipErrorInvalidValue;
+#else
     else     { if (twochild) VRT_GO(false, true); else VRT_GO(false, false); }
+#endif
 #undef VRT_GO
     return hipGetLastError();
 }
@@ -248,11 +260,18 @@ hipError_t vrt_launch_ray(const DevScene& S, const DevParams& P, bool bvh, bool 
     dim3 grid(1), block(64);
 #define VRT_GO(B, T) hipLaunchKernelGGL((k_ray<B, T>), grid, block, 0, stream, S, P, o[0], o[1], o[2], d[0], d[1], d[2], depth, rgba_out, hit_out, ctr)
     if (bvh) { if (twochild) VRT_GO(true, true); else VRT_GO(true, false); }
+#if VRT_SLAB_FMA
+    else return hipErrorInvalidValue;
+#else
     else     { if (twochild) VRT_GO(false, true); else VRT_GO(false, false); }
+#endif
 #undef VRT_GO
     return hipGetLastError();
 }
 
+} // namespace VRT_FORM
+
+#if !VRT_SLAB_FMA
 // ------------------------------------------------------------------ tone mapping after a gather
 
 __global__ __launch_bounds__(256) void k_tonemap(const float* __restrict__ rgb, float4* __restrict__ rgba, size_t n)
@@ -268,3 +287,4 @@ hipError_t vrt_launch_tonemap(const float* rgb, float4* rgba, size_t n, hipStrea
     hipLaunchKernelGGL(k_tonemap, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, rgb, rgba, n);
     return hipGetLastError();
 }
+#endif

@@ -2,23 +2,6 @@
 #pragma once
 #include "vrt_device.h"
 
-hipError_t vrt_launch_mega(const DevScene& S, const DevCam& cam, const DevParams& P, bool bvh, bool twochild,
-                           float4* rgba, int* hit_id, unsigned long long* ctr, hipStream_t stream);
-
-// The megakernel for tree scenes with one child ray per hit, bounces compacted inside blocks of
-// four waves (vrt_blockwf.hip).  Same frame, hit ids and ray counts as vrt_launch_mega.
-hipError_t vrt_launch_mega_blk(const DevScene& S, const DevCam& cam, const DevParams& P, float4* rgba, int* hit_id,
-                               unsigned long long* ctr, hipStream_t stream);
-
-hipError_t vrt_launch_pixels(const DevScene& S, const DevCam& cam, const DevParams& P, bool bvh, bool twochild,
-                             const int* pixels, int n_pixels, int sample_sel, vrt_path_seg* segs, int cap,
-                             int* seg_counts, float4* rgba_out, int* hit_out, unsigned long long* ctr,
-                             hipStream_t stream);
-
-hipError_t vrt_launch_ray(const DevScene& S, const DevParams& P, bool bvh, bool twochild, const float o[3],
-                          const float d[3], int depth, float4* rgba_out, int* hit_out, unsigned long long* ctr,
-                          hipStream_t stream);
-
 // The persistent kernels of the wavefront pipeline run at most VRT_WF_MAX_BLOCKS blocks of four
 // waves; a wave takes queue entries VRT_WF_CHUNK at a time and may leave its last chunk partly
 // unwritten, so queues are allocated VRT_WF_SLACK entries longer than the rays they must hold.
@@ -47,9 +30,38 @@ struct WfWorkspace {
     int refill;         // BVH scenes: trace queues with k_wf_trace (lanes refilled as they finish)
 };
 
-hipError_t vrt_launch_wavefront(const DevScene& S, const DevCam& cam, const DevParams& P, bool bvh,
-                                bool twochild, const WfWorkspace& W, float4* rgba, int* hit_id,
-                                unsigned long long* ctr, hipStream_t stream);
+// The launchers exist twice, in namespaces vrt_plain and vrt_fused: the kernel sources are
+// compiled once as they are and once with -DVRT_SLAB_FMA=1 (the 4-wide box test in its fused
+// form, see slab4 in vrt_trace.h), and VRT_FORM names the namespace of the compilation at hand.
+// The fused set serves tree scenes only (bvh = true; anything else is hipErrorInvalidValue).
+#if defined(VRT_SLAB_FMA) && VRT_SLAB_FMA
+#define VRT_FORM vrt_fused
+#else
+#define VRT_FORM vrt_plain
+#endif
+#define VRT_LAUNCHERS \
+    hipError_t vrt_launch_mega(const DevScene& S, const DevCam& cam, const DevParams& P, bool bvh, bool twochild, \
+                               float4* rgba, int* hit_id, unsigned long long* ctr, hipStream_t stream); \
+    \
+    hipError_t vrt_launch_mega_blk(const DevScene& S, const DevCam& cam, const DevParams& P, float4* rgba, int* hit_id, \
+                                   unsigned long long* ctr, hipStream_t stream); \
+    \
+    hipError_t vrt_launch_pixels(const DevScene& S, const DevCam& cam, const DevParams& P, bool bvh, bool twochild, \
+                                 const int* pixels, int n_pixels, int sample_sel, vrt_path_seg* segs, int cap, \
+                                 int* seg_counts, float4* rgba_out, int* hit_out, unsigned long long* ctr, \
+                                 hipStream_t stream); \
+    \
+    hipError_t vrt_launch_ray(const DevScene& S, const DevParams& P, bool bvh, bool twochild, const float o[3], \
+                              const float d[3], int depth, float4* rgba_out, int* hit_out, unsigned long long* ctr, \
+                              hipStream_t stream); \
+    \
+    hipError_t vrt_launch_wavefront(const DevScene& S, const DevCam& cam, const DevParams& P, bool bvh, \
+                                    bool twochild, const WfWorkspace& W, float4* rgba, int* hit_id, \
+                                    unsigned long long* ctr, hipStream_t stream); \
+
+namespace vrt_plain { VRT_LAUNCHERS }
+namespace vrt_fused { VRT_LAUNCHERS }
+#undef VRT_LAUNCHERS
 
 // LBVH build on the device.  prim arrays are those of DevScene; writes 4*(n_prims-1) float4
 // binary nodes (with parent indices) to `nodes` and 8*(n_prims-1) float4 of 4-wide nodes to `wide`

@@ -343,6 +343,7 @@ __device__ __forceinline__ void count_lanes(const DevScene& S, int k, bool mine 
 // One ray on its way through the tree.
 struct Trav {
     f3 o, d, inv;
+    f3 oi;                  // what slab4 subtracts: the origin, or -(origin * inv) in the fused form
     float maxd, tlim, lim0; // range of the query, "nearer than" bound of an any-hit query, min of both
     int skip;               // primitive the ray was spawned on
     Hit best;
@@ -353,7 +354,17 @@ struct Trav {
 
 __device__ __forceinline__ void trav_begin(Trav& T, f3 o, f3 d, float maxd, float tlim, int skip)
 {
-    T.o = o; T.d = d; T.inv = mk3(1.f / d.x, 1.f / d.y, 1.f / d.z);
+    T.o = o; T.d = d;
+#if VRT_SLAB_FMA
+    // box tests only produce candidates, so the reciprocal need not be the correctly rounded one
+    T.inv = mk3(__builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.x), -1e30f, 1e30f),
+                __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.y), -1e30f, 1e30f),
+                __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.z), -1e30f, 1e30f));
+    T.oi = mk3(-(o.x * T.inv.x), -(o.y * T.inv.y), -(o.z * T.inv.z));
+#else
+    T.inv = mk3(1.f / d.x, 1.f / d.y, 1.f / d.z);
+    T.oi = o;
+#endif
     T.maxd = maxd; T.tlim = tlim; T.lim0 = fminf(maxd, tlim); T.skip = skip;
     T.best.t = INFINITY; T.best.prim = -1; T.best.aux = 0;
     T.node = 0; T.sp = 0; T.ovf = false;
@@ -365,18 +376,36 @@ __device__ __forceinline__ float trav_limit(const Trav& T) { return T.best.prim 
 // The four slab tests of slab_test() on one 128-byte node, children (0,1) and (2,3) as packed
 // pairs (v_pk_add_f32 / v_pk_mul_f32).  Unused child slots hold boxes at +inf, which no ray passes.
 struct Slab4 { float t0, t1, t2, t3; bool h0, h1, h2, h3; };
+// Every kernel that walks the tree is compiled twice (see VRT_FORM in vrt_launch.h).  With
+// VRT_SLAB_FMA the box test is plane * inv - origin * inv in one fused step per pair of planes
+// (v_pk_fma_f32, `o` then holds -(origin * inv)) instead of (plane - origin) * inv: 12 instead of
+// 24 packed instructions per node.  The fused form rounds origin * inv before the subtraction, an
+// absolute error of 2^-24 |origin| |inv|; the boxes are padded by 1e-4 (1 + |plane|), so a
+// candidate cannot be lost while ray origins stay within +-1600 of the coordinate origin, which
+// the host checks per frame before it picks the fused kernels.  inv is clamped to +-1e30 in that
+// form (trav_begin): a zero direction component would otherwise give inf - inf for a slab the ray
+// runs inside of.
+#ifndef VRT_SLAB_FMA
+#define VRT_SLAB_FMA 0
+#endif
+#if VRT_SLAB_FMA
+#define VRT_PLANE(P0, P1, I, C) __builtin_elementwise_fma(v2f{P0, P1}, I, C)
+#else
+#define VRT_PLANE(P0, P1, I, C) ((v2f{P0, P1} - C) * I)
+#endif
 __device__ __forceinline__ Slab4 slab4(float4 lx, float4 ly, float4 lz, float4 hx, float4 hy, float4 hz, f3 o, f3 inv,
                                        float lim)
 {
     Slab4 r;
-    const v2f ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
     const v2f ix = {inv.x, inv.x}, iy = {inv.y, inv.y}, iz = {inv.z, inv.z};
-    const v2f ax01 = (v2f{lx.x, lx.y} - ox) * ix, ax23 = (v2f{lx.z, lx.w} - ox) * ix;
-    const v2f bx01 = (v2f{hx.x, hx.y} - ox) * ix, bx23 = (v2f{hx.z, hx.w} - ox) * ix;
-    const v2f ay01 = (v2f{ly.x, ly.y} - oy) * iy, ay23 = (v2f{ly.z, ly.w} - oy) * iy;
-    const v2f by01 = (v2f{hy.x, hy.y} - oy) * iy, by23 = (v2f{hy.z, hy.w} - oy) * iy;
-    const v2f az01 = (v2f{lz.x, lz.y} - oz) * iz, az23 = (v2f{lz.z, lz.w} - oz) * iz;
-    const v2f bz01 = (v2f{hz.x, hz.y} - oz) * iz, bz23 = (v2f{hz.z, hz.w} - oz) * iz;
+    const v2f ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
+    const v2f ax01 = VRT_PLANE(lx.x, lx.y, ix, ox), ax23 = VRT_PLANE(lx.z, lx.w, ix, ox);
+    const v2f bx01 = VRT_PLANE(hx.x, hx.y, ix, ox), bx23 = VRT_PLANE(hx.z, hx.w, ix, ox);
+    const v2f ay01 = VRT_PLANE(ly.x, ly.y, iy, oy), ay23 = VRT_PLANE(ly.z, ly.w, iy, oy);
+    const v2f by01 = VRT_PLANE(hy.x, hy.y, iy, oy), by23 = VRT_PLANE(hy.z, hy.w, iy, oy);
+    const v2f az01 = VRT_PLANE(lz.x, lz.y, iz, oz), az23 = VRT_PLANE(lz.z, lz.w, iz, oz);
+    const v2f bz01 = VRT_PLANE(hz.x, hz.y, iz, oz), bz23 = VRT_PLANE(hz.z, hz.w, iz, oz);
+#undef VRT_PLANE
 #define VRT_SLAB4(T, H, AX, BX, AY, BY, AZ, BZ)                                                       \
     {                                                                                                 \
         float n_ = fmaxf(fmaxf(fminf(AX, BX), fminf(AY, BY)), fmaxf(fminf(AZ, BZ), 0.f));             \
@@ -411,7 +440,7 @@ __device__ __forceinline__ bool trav_inner(const DevScene& S, Trav& T, unsigned 
     const float4* n = S.bvh4 + 8 * (size_t)T.node;
     const float4 lx = n[0], ly = n[1], lz = n[2], hx = n[3], hy = n[4], hz = n[5], cc = n[6];
     int c0 = __float_as_int(cc.x), c1 = __float_as_int(cc.y), c2 = __float_as_int(cc.z), c3 = __float_as_int(cc.w);
-    Slab4 r = slab4(lx, ly, lz, hx, hy, hz, T.o, T.inv, trav_limit(T));
+    Slab4 r = slab4(lx, ly, lz, hx, hy, hz, T.oi, T.inv, trav_limit(T));
     if (any) {
         bool taken = false;
 #define VRT_VISIT_ANY(H, C) if (H) { if (!taken) { T.node = C; taken = true; } else trav_push(S, T, my_lds, 0.f, C); }
@@ -565,7 +594,7 @@ __device__ __forceinline__ bool intersect_bvh4_packet(const DevScene& S, Trav& T
             const float4* n = S.bvh4 + 8 * (size_t)node;
             const float4 lx = n[0], ly = n[1], lz = n[2], hx = n[3], hy = n[4], hz = n[5], cc = n[6];
             const float lim = found ? -INFINITY : (best.prim >= 0 ? best.t : T.lim0);
-            const Slab4 r = slab4(lx, ly, lz, hx, hy, hz, T.o, T.inv, lim);
+            const Slab4 r = slab4(lx, ly, lz, hx, hy, hz, T.oi, T.inv, lim);
             const unsigned long long m0 = __ballot(r.h0), m1 = __ballot(r.h1), m2 = __ballot(r.h2), m3 = __ballot(r.h3);
             // order key of a child: entry distance of the first lane that passes its box (bits of a
             // non-negative float compare like integers); no lane: never entered

@@ -30,6 +30,7 @@
 #include "vrt_trace.h"
 #include "vrt_launch.h"
 
+namespace VRT_FORM {
 namespace {
 
 // Slot for this lane's ray in the output queue, or -1.  Must be called by the whole wave.
@@ -601,6 +602,12 @@ hipError_t vrt_launch_wavefront(const DevScene& S, const DevCam& cam, const DevP
     if (e != hipSuccess) return e;
     if (bvh) return twochild ? run<true, true>(S, cam, P, W, rgba, hit_id, ctr, stream)
                              : run<true, false>(S, cam, P, W, rgba, hit_id, ctr, stream);
+#if VRT_SLAB_FMA
+    return hipErrorInvalidValue;   // the fused form only differs where a tree is walked
+#else
     return twochild ? run<false, true>(S, cam, P, W, rgba, hit_id, ctr, stream)
                     : run<false, false>(S, cam, P, W, rgba, hit_id, ctr, stream);
+#endif
 }
+
+} // namespace VRT_FORM

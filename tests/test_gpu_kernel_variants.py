@@ -237,3 +237,62 @@ def test_stackless_finish_gives_the_same_frame(vrt_ctx, vrt_opts, which, cap):
     px = vrt_ctx.trace_pixel(ra.Params(**kw), 30, 60, -1, 128)   # state machine, four lanes per ray
     assert px[3] == ref_px[3] and bytes(px[2])[:px[3] * 40] == bytes(ref_px[2])[:px[3] * 40]
     assert np.array_equal(px[0], ref_px[0], equal_nan=True)
+
+
+@pytest.mark.parametrize("which", ["spheres", "mesh"])
+def test_fused_box_test_gives_the_same_frame(vrt_ctx, vrt_opts, which):
+    """Tree scenes near the coordinate origin take the box test in its fused form (plane * inv -
+    origin * inv, reciprocals clamped); it may only ever add candidates, so frames, hit ids, ray
+    counts and recorded ray trees are those of the subtract-then-multiply form.  The sphere scene
+    has a ground box whose ambient-occlusion and reflected rays run exactly along an axis
+    (direction components of exactly zero, reciprocal infinite)."""
+    if which == "spheres":
+        scene, cam, rng = ra.random_spheres_scene(n=1500, seed=3), ra.random_spheres_camera(120, 68), 200.0
+    else:
+        scene, cam, rng = ra.tessellated_mesh_scene(quads=40), ra.tessellated_mesh_camera(120, 68), 100.0
+    offs = host.sampler_table(abi.VRT_SAMPLER_JITTERED, 4, 3, 0.02, 0.02, seed=5)
+    kw = dict(spp=4, offsets=offs, seed=2, max_depth=5, rng=rng)
+    vrt_ctx.set_scene(scene)
+    vrt_ctx.set_camera(cam)
+    frames = {}
+    for fma in (0, 1):
+        vrt_opts("slab_fma", fma)
+        for mode in (abi.VRT_MODE_MEGAKERNEL, abi.VRT_MODE_WAVEFRONT):
+            for packet in (0, 1):
+                vrt_opts("packet", packet)
+                frames[(fma, mode, packet)] = vrt_ctx.render(ra.Params(mode=mode, **kw))
+        frames[(fma, "px")] = vrt_ctx.trace_pixel(ra.Params(**kw), 30, 60, -1, 128)
+    ref, ref_hit, ref_st = frames[(0, abi.VRT_MODE_MEGAKERNEL, 0)]
+    for key, val in frames.items():
+        if key[1] == "px":
+            continue
+        got, got_hit, st = val
+        assert np.array_equal(got, ref, equal_nan=True) and np.array_equal(got_hit, ref_hit), key
+        assert list(st.rays) == list(ref_st.rays), key
+    a, b = frames[(0, "px")], frames[(1, "px")]
+    assert a[3] == b[3] and bytes(a[2])[:a[3] * 40] == bytes(b[2])[:b[3] * 40]
+    assert np.array_equal(a[0], b[0], equal_nan=True)
+
+
+def test_scene_far_from_the_origin_keeps_the_plain_box_test(vrt_ctx, oracle_mod):
+    """The fused box test is only proven for ray origins within +-1600 of the coordinate origin; a
+    scene (or camera) beyond that is traced with the plain form.  The same spheres moved some
+    thousand units away, seen by a camera moved with them, must still match the oracle's hit ids,
+    ray counts and colours."""
+    scene = ra.random_spheres_scene(n=600, seed=9)
+    cam = ra.random_spheres_camera(64, 36)
+    shift = np.array([5000.0, 0.0, -4096.0], np.float32)
+    scene.spheres["center"] += shift
+    scene.boxes["center"] += shift
+    scene.lights["location"] += shift
+    far_cam = ra.make_camera(np.array(cam.origin[:]) + shift, np.array(cam.p0[:]) + shift, cam.x_axis[:], cam.y_axis[:],
+                             cam.width, cam.height)
+    prm = ra.Params(spp=1, seed=1, max_depth=3, rng=200.0)
+    vrt_ctx.set_scene(scene)
+    vrt_ctx.set_camera(far_cam)
+    got, got_hit, st = vrt_ctx.render(prm)
+    ref, ref_hit, ref_rays = oracle_mod.render(scene, far_cam, prm.c, n_threads=8)
+    assert (got_hit >= 0).sum() > 500
+    assert np.array_equal(got_hit, ref_hit)
+    assert np.array_equal(np.array(st.rays[:], np.uint64), ref_rays)
+    assert np.abs(got - ref).max() <= 1.0 / 255.0
