@@ -420,6 +420,37 @@ __device__ __forceinline__ Slab4 slab4(float4 lx, float4 ly, float4 lz, float4 h
     return r;
 }
 
+#if VRT_SLAB_FMA
+// slab4 with the entry planes (n*) and exit planes (f*) of the four children already told apart.
+__device__ __forceinline__ Slab4 slab4_signed(float4 nx, float4 ny, float4 nz, float4 fx, float4 fy, float4 fz, f3 c,
+                                              f3 inv, float lim)
+{
+    Slab4 r;
+    const v2f ix = {inv.x, inv.x}, iy = {inv.y, inv.y}, iz = {inv.z, inv.z};
+    const v2f cx = {c.x, c.x}, cy = {c.y, c.y}, cz = {c.z, c.z};
+#define VRT_PLANE(P0, P1, I, C) __builtin_elementwise_fma(v2f{P0, P1}, I, C)
+    const v2f ax01 = VRT_PLANE(nx.x, nx.y, ix, cx), ax23 = VRT_PLANE(nx.z, nx.w, ix, cx);
+    const v2f bx01 = VRT_PLANE(fx.x, fx.y, ix, cx), bx23 = VRT_PLANE(fx.z, fx.w, ix, cx);
+    const v2f ay01 = VRT_PLANE(ny.x, ny.y, iy, cy), ay23 = VRT_PLANE(ny.z, ny.w, iy, cy);
+    const v2f by01 = VRT_PLANE(fy.x, fy.y, iy, cy), by23 = VRT_PLANE(fy.z, fy.w, iy, cy);
+    const v2f az01 = VRT_PLANE(nz.x, nz.y, iz, cz), az23 = VRT_PLANE(nz.z, nz.w, iz, cz);
+    const v2f bz01 = VRT_PLANE(fz.x, fz.y, iz, cz), bz23 = VRT_PLANE(fz.z, fz.w, iz, cz);
+#undef VRT_PLANE
+#define VRT_SLAB4(T, H, AX, BX, AY, BY, AZ, BZ)                       \
+    {                                                                 \
+        float n_ = fmaxf(fmaxf(AX, AY), fmaxf(AZ, 0.f));              \
+        float f_ = fminf(fminf(BX, BY), fminf(BZ, lim));              \
+        T = n_; H = n_ <= f_ * 1.0000004f;                            \
+    }
+    VRT_SLAB4(r.t0, r.h0, ax01.x, bx01.x, ay01.x, by01.x, az01.x, bz01.x)
+    VRT_SLAB4(r.t1, r.h1, ax01.y, bx01.y, ay01.y, by01.y, az01.y, bz01.y)
+    VRT_SLAB4(r.t2, r.h2, ax23.x, bx23.x, ay23.x, by23.x, az23.x, bz23.x)
+    VRT_SLAB4(r.t3, r.h3, ax23.y, bx23.y, ay23.y, by23.y, az23.y, bz23.y)
+#undef VRT_SLAB4
+    return r;
+}
+#endif
+
 __device__ __forceinline__ void trav_push(const DevScene& S, Trav& T, unsigned long long* my_lds, float tnear, int code)
 {
     if (T.sp < S.stack_cap) {   // VRT_TRAV_STACK unless a test shortens it
@@ -437,10 +468,29 @@ __device__ __forceinline__ void trav_push(const DevScene& S, Trav& T, unsigned l
 __device__ __forceinline__ bool trav_inner(const DevScene& S, Trav& T, unsigned long long* my_lds, bool any)
 {
     count_lanes(S, 6);
+#if VRT_SLAB_FMA
+    // Entry and exit planes picked by the sign of the direction at load time, instead of loading
+    // both and taking min and max: a node is lo.x, lo.y, lo.z, hi.x, hi.y, hi.z (16 bytes each, four
+    // children wide) and the entry plane of an axis is lo for a positive direction, hi for a
+    // negative one, 48 bytes further on.  No NaN can arise in the fused form (planes are finite or
+    // +inf, inv is finite and not zero), so the distances are those of the min/max form bit for bit.
+    const char* base = (const char*)S.bvh4;
+    const unsigned at = (unsigned)T.node << 7;
+    const unsigned ex = at + (__float_as_uint(T.inv.x) >> 31) * 48u;
+    const unsigned ey = at + 16u + (__float_as_uint(T.inv.y) >> 31) * 48u;
+    const unsigned ez = at + 32u + (__float_as_uint(T.inv.z) >> 31) * 48u;
+    const float4 nx = *(const float4*)(base + ex), ny = *(const float4*)(base + ey), nz = *(const float4*)(base + ez);
+    const float4 fx = *(const float4*)(base + (ex ^ 48u)), fy = *(const float4*)(base + (ey ^ 80u)),
+                 fz = *(const float4*)(base + (ez ^ 112u));
+    const float4 cc = *(const float4*)(base + (at + 96u));
+    int c0 = __float_as_int(cc.x), c1 = __float_as_int(cc.y), c2 = __float_as_int(cc.z), c3 = __float_as_int(cc.w);
+    Slab4 r = slab4_signed(nx, ny, nz, fx, fy, fz, T.oi, T.inv, trav_limit(T));
+#else
     const float4* n = S.bvh4 + 8 * (size_t)T.node;
     const float4 lx = n[0], ly = n[1], lz = n[2], hx = n[3], hy = n[4], hz = n[5], cc = n[6];
     int c0 = __float_as_int(cc.x), c1 = __float_as_int(cc.y), c2 = __float_as_int(cc.z), c3 = __float_as_int(cc.w);
     Slab4 r = slab4(lx, ly, lz, hx, hy, hz, T.oi, T.inv, trav_limit(T));
+#endif
     if (any) {
         bool taken = false;
 #define VRT_VISIT_ANY(H, C) if (H) { if (!taken) { T.node = C; taken = true; } else trav_push(S, T, my_lds, 0.f, C); }
