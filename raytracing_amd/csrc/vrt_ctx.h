@@ -10,7 +10,7 @@
 
 // Study and test knobs.  Environment variables of the same meaning (VRT_XCD_REMAP, VRT_SAMPLE_SHIFT,
 // VRT_WF_DEFER, VRT_WF_REFILL, VRT_WF_MAX_SLOTS, VRT_WF_ANY_CAP, VRT_BUILDER, VRT_COLLAPSE_PARITY,
-// VRT_NO_BIG, VRT_PACKET, VRT_BLOCK_COMPACT, VRT_SLAB_FMA) are read once, when the context is created; vrt_set_option changes
+// VRT_NO_BIG, VRT_PACKET, VRT_BEAM, VRT_BLOCK_COMPACT, VRT_SLAB_FMA) are read once, when the context is created; vrt_set_option changes
 // them afterwards.  Nothing on the per-frame path reads the environment.
 struct VrtOptions {
     int xcd_remap = 0;          // 1: each XCD renders one contiguous band of tiles (measured slower)
@@ -24,6 +24,7 @@ struct VrtOptions {
     int collapse_parity = 0;    // 1: collapse every second level instead of by surface area
     int no_big = 0;             // 1: scene-sized primitives stay in the tree
     int packet = -1;            // tree scenes: wave-uniform traversal for the rays of one pixel group; -1 = chosen from spp
+    int beam = -1;              // tree scenes, megakernel: camera rays of a wave collect their candidate leaves together; -1 = chosen from the lanes per pixel
     int quad_max = -1;          // tree scenes: waves with at most this many queries trace them four lanes per ray; -1 = library default
     int slab_fma = 1;           // tree scenes: fused box test where the scene lies near enough to the origin for it (0: never)
     int stack_cap = 0;          // tests: traversal-stack entries per lane (0 = all the kernels have), forces the stackless finish

@@ -96,6 +96,7 @@ struct DevParams {
     int packet;       // tree scenes: rays a wave casts together take the wave-uniform traversal first
     int general;      // the scene or the flags need the general kernels: two children per hit, matte / transparent materials
     int quad_max;     // tree scenes: a wave with at most this many queries traces them four lanes per ray (0 = never)
+    int beam;         // tree scenes, megakernel: the camera rays of a wave collect their candidate leaves together first
 };
 
 // Per-call ray counters: 256 slots x 8 words to spread atomic traffic, summed by the host.

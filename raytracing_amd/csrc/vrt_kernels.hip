@@ -25,6 +25,9 @@
 namespace VRT_FORM {
 
 #define VRT_MEGA_THREADS 64
+#ifndef VRT_WAVE_PRIMARY
+#define VRT_WAVE_PRIMARY 1
+#endif
 #ifndef VRT_BVH_WAVES
 #define VRT_BVH_WAVES 4
 #endif
@@ -94,6 +97,12 @@ __global__ __launch_bounds__(VRT_MEGA_THREADS, BVH ? VRT_BVH_WAVES : (SIMPLE ? V
             int fp;
             c = trace_samples_sm<BVH, false, TWOCHILD>(S, cam, P, &s_scene, act ? h : 0, act ? v : 0, act ? i : 0, act ? i + 1 : 0, fp, C, R);
             if (act && i == 0) id = fp;
+        } else if (BVH) {
+            // the whole wave goes in, so that the camera rays can be traced cooperatively
+            const bool live = inside && i < P.spp;
+            int fp;
+            c = trace_sample_dev<BVH, false, TWOCHILD>(S, cam, P, raw, off, i, fp, C, R, live, VRT_WAVE_PRIMARY != 0);
+            if (live && i == 0) id = fp;
         } else if (inside && i < P.spp) {
             int fp;
             c = trace_sample_dev<BVH, false, TWOCHILD>(S, cam, P, raw, off, i, fp, C, R);

@@ -44,6 +44,31 @@ __device__ __forceinline__ f3 normalize3(f3 a)
 __device__ __forceinline__ bool is_zero3(f3 a) { return a.x == 0.f && a.y == 0.f && a.z == 0.f; }
 __device__ __forceinline__ f3 xyz(float4 v) { return mk3(v.x, v.y, v.z); }
 
+// Load of scene data (primitives, tree nodes, materials, lights: written by the host before the
+// launch, never by a kernel) through the constant address space.  A wave-uniform address then
+// always becomes a scalar load; from the global address space it only does while the compiler can
+// prove that nothing in the kernel may write that memory, which a single call or a store through a
+// generic pointer anywhere in the kernel ends (every node of the wave-uniform traversal and every
+// primitive of the brute-force loop then comes through the vector memory path, +10 % frame time).
+#define VRT_CONST_AS __attribute__((address_space(4)))
+__device__ __forceinline__ float4 ldc(const float4* p)
+{
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const v4f v = *(const VRT_CONST_AS v4f*)p;
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ int ldc(const int* p) { return *(const VRT_CONST_AS int*)p; }
+__device__ __forceinline__ DevLight ldc(const DevLight* p)
+{
+    static_assert(sizeof(DevLight) % 4 == 0, "DevLight is copied word by word");
+    DevLight l;
+    int* w = (int*)&l;
+    const VRT_CONST_AS int* q = (const VRT_CONST_AS int*)p;
+#pragma unroll
+    for (int k = 0; k < (int)(sizeof(DevLight) / 4); ++k) w[k] = q[k];
+    return l;
+}
+
 // Same mixing function as vrt_pixel_set on the host.
 __device__ __forceinline__ unsigned pixel_set_dev(unsigned seed, unsigned pixel, unsigned n_sets)
 {
@@ -184,13 +209,13 @@ __device__ __forceinline__ void test_prim(const DevScene& S, int id, f3 o, f3 d,
 {
     float t; int aux = 0; bool h;
     if (id < S.n_sph) {
-        h = hit_sphere(S.sph[id], o, d, maxd, t);
+        h = hit_sphere(ldc(S.sph + id), o, d, maxd, t);
     } else if (id < S.n_sph + S.n_box) {
         const float4* b = S.box + 4 * (id - S.n_sph);
-        h = hit_box(b[0], b[1], b[2], b[3], o, d, maxd, t, aux);
+        h = hit_box(ldc(b), ldc(b + 1), ldc(b + 2), ldc(b + 3), o, d, maxd, t, aux);
     } else {
         const float4* tr = S.tri + 3 * (size_t)(id - S.n_sph - S.n_box);
-        h = hit_tri(xyz(tr[0]), xyz(tr[1]), xyz(tr[2]), o, d, maxd, t);
+        h = hit_tri(xyz(ldc(tr)), xyz(ldc(tr + 1)), xyz(ldc(tr + 2)), o, d, maxd, t);
     }
     if (h && (t < best.t || (t == best.t && id < best.prim) || best.prim < 0)) {
         best.t = t; best.prim = id; best.aux = aux;
@@ -222,9 +247,9 @@ __device__ __forceinline__ void stage_prims(const DevScene& S)
 #define VRT_PRE(i) g_lds_pre[i]
 #else
 __device__ __forceinline__ void stage_prims(const DevScene&) {}
-#define VRT_SPH(i) S.sph[i]
-#define VRT_AAB(i) S.aab[i]
-#define VRT_PRE(i) S.cam_pre[i]
+#define VRT_SPH(i) ldc(S.sph + (i))
+#define VRT_AAB(i) ldc(S.aab + (i))
+#define VRT_PRE(i) ldc(S.cam_pre + (i))
 #endif
 
 // CAM: the ray starts at the camera origin and S.cam_pre holds the per-primitive terms that
@@ -271,13 +296,13 @@ __device__ __forceinline__ Hit intersect_brute(const DevScene& S, f3 o, f3 d, fl
             // Conservative cull: b[3].w = squared circumradius of the box.  A ray that clears the
             // circumsphere (with 32 ulp of |oc|^2 slack for rounding) cannot touch the box; when
             // no lane of the wave can, the slab test with its three divisions is skipped.
-            float4 bc = b[0];
+            float4 bc = ldc(b);
             f3 oc = o - xyz(bc);
             float oo = dot3(oc, oc), bb = dot3(oc, d);
-            float cs = oo - b[3].w, slack = 4e-6f * oo;
+            float cs = oo - ldc(b + 3).w, slack = 4e-6f * oo;
             bool may = !((bb * bb - cs + slack < 0.f) || (cs > slack && bb > 0.f));
             if (!__any(may)) continue;
-            if (i + S.n_sph != skip && hit_box(b[0], b[1], b[2], b[3], o, d, maxd, t, aux) && t < best.t && t < tlim) {
+            if (i + S.n_sph != skip && hit_box(ldc(b), ldc(b + 1), ldc(b + 2), ldc(b + 3), o, d, maxd, t, aux) && t < best.t && t < tlim) {
                 best.t = t; best.prim = i + S.n_sph; best.aux = aux;
                 if (ANY) return best;
             }
@@ -287,7 +312,7 @@ __device__ __forceinline__ Hit intersect_brute(const DevScene& S, f3 o, f3 d, fl
         float t;
         const float4* tr = S.tri + 3 * (size_t)i;
         if (i + S.n_sph + S.n_box != skip &&
-            hit_tri(xyz(tr[0]), xyz(tr[1]), xyz(tr[2]), o, d, maxd, t) && t < best.t && t < tlim) {
+            hit_tri(xyz(ldc(tr)), xyz(ldc(tr + 1)), xyz(ldc(tr + 2)), o, d, maxd, t) && t < best.t && t < tlim) {
             best.t = t; best.prim = i + S.n_sph + S.n_box;
             if (ANY) return best;
         }
@@ -597,25 +622,31 @@ __device__ __forceinline__ bool trav_stackless(const DevScene& S, Trav& T, bool 
 // since.  The result does not depend on the visiting order because candidates are ranked by (t, id).
 __device__ __forceinline__ bool intersect_bvh4_packet(const DevScene& S, Trav& T, bool live, bool any);
 
+// The tree part of a query that has been through trav_begin and trav_big.
+__device__ __forceinline__ void intersect_bvh4_tree(const DevScene& S, Trav& T, bool any, bool packet)
+{
+    unsigned long long* my_lds = g_lds_stack + threadIdx.x;
+    if (packet && intersect_bvh4_packet(S, T, true, any)) return;
+    // every node is entered at most once; the bound only guards against a corrupt tree
+    for (int guard = 2 * S.n_prims + 8; guard > 0; --guard) {
+        bool pop;
+        if (T.node >= 0) pop = trav_inner(S, T, my_lds, any);
+        else { if (trav_leaf(S, T, any)) return; pop = true; }
+        if (pop && !trav_pop(T, my_lds)) break;
+    }
+    if (T.ovf) trav_stackless(S, T, any);
+}
+
 // packet: the calling lanes' rays are expected to stay close to each other and try the
 // wave-uniform traversal first (intersect_bvh4_packet).
 __device__ __forceinline__ Hit intersect_bvh4(const DevScene& S, f3 o, f3 d, float maxd, float tlim, int skip, bool any,
                                               bool packet = false)
 {
-    unsigned long long* my_lds = g_lds_stack + threadIdx.x;
     Trav T;
     trav_begin(T, o, d, maxd, tlim, skip);
     if (is_zero3(d)) return T.best;
     if (trav_big(S, T, any)) return T.best;
-    if (packet && intersect_bvh4_packet(S, T, true, any)) return T.best;
-    // every node is entered at most once; the bound only guards against a corrupt tree
-    for (int guard = 2 * S.n_prims + 8; guard > 0; --guard) {
-        bool pop;
-        if (T.node >= 0) pop = trav_inner(S, T, my_lds, any);
-        else { if (trav_leaf(S, T, any)) return T.best; pop = true; }
-        if (pop && !trav_pop(T, my_lds)) break;
-    }
-    if (T.ovf) trav_stackless(S, T, any);
+    intersect_bvh4_tree(S, T, any, packet);
     return T.best;
 }
 
@@ -641,8 +672,10 @@ __device__ __forceinline__ bool intersect_bvh4_packet(const DevScene& S, Trav& T
         bool pop = true;
         if (node >= 0) {
             count_lanes(S, 6);
-            const float4* n = S.bvh4 + 8 * (size_t)node;
-            const float4 lx = n[0], ly = n[1], lz = n[2], hx = n[3], hy = n[4], hz = n[5], cc = n[6];
+            // (readfirstlane: the index is wave-uniform by construction; said again so that the node
+            // comes through scalar loads whatever the compiler's uniformity analysis makes of the loop)
+            const float4* n = S.bvh4 + 8 * (size_t)__builtin_amdgcn_readfirstlane(node);
+            const float4 lx = ldc(n), ly = ldc(n + 1), lz = ldc(n + 2), hx = ldc(n + 3), hy = ldc(n + 4), hz = ldc(n + 5), cc = ldc(n + 6);
             const float lim = found ? -INFINITY : (best.prim >= 0 ? best.t : T.lim0);
             const Slab4 r = slab4(lx, ly, lz, hx, hy, hz, T.oi, T.inv, lim);
             const unsigned long long m0 = __ballot(r.h0), m1 = __ballot(r.h1), m2 = __ballot(r.h2), m3 = __ballot(r.h3);
@@ -674,7 +707,7 @@ __device__ __forceinline__ bool intersect_bvh4_packet(const DevScene& S, Trav& T
                 node = __builtin_amdgcn_readfirstlane(cf);
             }
         } else {
-            const int id = ~node;
+            const int id = __builtin_amdgcn_readfirstlane(~node);
             count_lanes(S, 7);
             if (!found && id != T.skip) test_prim(S, id, T.o, T.d, T.maxd, best);
             if (any && !found && best.prim >= 0) {
@@ -702,6 +735,152 @@ __device__ __forceinline__ bool intersect_bvh4_packet(const DevScene& S, Trav& T
     return true;
 }
 
+
+// ------------------------------------------------------------------ beam: candidates once per wave
+//
+// Camera rays of a wave (one pixel x 64 samples, or a few neighbouring pixels) leave one point in
+// almost one direction.  Instead of every lane testing the same four boxes with its own ray at
+// every node, the wave walks the tree ONCE with a conservative bound of all its rays, and uses its
+// lanes for different boxes: 16 nodes of a frontier at a time, lane 4k+c testing child c of node
+// k.  The bound is interval arithmetic on the slab test: with the reciprocal direction of every
+// live lane inside [ilo, ihi] per axis (same sign, else the axis does not constrain) and the
+// common origin, a child is entered when max_axis(lower bound of the entry distance) <=
+// min_axis(upper bound of the exit distance), which holds for every box some ray of the wave
+// passes.  Inner children go back to the frontier, leaves to a candidate list; afterwards every
+// lane tests its own ray against every candidate, and the ranking by (t, id) makes the result the
+// one of the lane's own traversal.  There is no front-to-back order and no pruning by hits found
+// on the way (only by the range, and by hits on the primitives kept out of the tree), so a beam
+// collects more leaves than a ray visits (5-8 against 3 on the 10 k-sphere frame) but takes 3-5
+// frontier steps instead of 16 node steps.  All 64 lanes must call; live = this lane holds a ray.
+// Returns false, with nothing changed, when frontier or candidate list would overflow (a wide
+// beam): the caller then traverses as usual.
+#ifndef VRT_BEAM
+#define VRT_BEAM 1
+#endif
+#ifndef VRT_BEAM_FRONT
+#define VRT_BEAM_FRONT 80
+#endif
+#ifndef VRT_BEAM_CAND
+#define VRT_BEAM_CAND 48
+#endif
+// Frontier and candidate list live in the wave's columns of the traversal stack, which is idle
+// while the beam runs: slot k = row k / 64, column k % 64 of the wave.
+__device__ __forceinline__ int* beam_slot(int k)
+{
+    return (int*)&g_lds_stack[(k >> 6) * VRT_STACK_LANES + (threadIdx.x & ~63) + (k & 63)];
+}
+
+__device__ __forceinline__ void wave_lds_fence_()
+{
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ float wave_min_f(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_max_f(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// The collection pass.  Not inlined on purpose: compiled into the frame kernel it changed the
+// register allocation of every traversal loop there (10 % on frames that never take the beam).
+// Takes what it needs by value (a reference to the scene would force the scene into memory).
+// Returns the number of candidates, now in beam_slot(VRT_BEAM_FRONT + k), or -1 on overflow.
+__device__ __noinline__ int beam_collect(const float4* bvh4, int n_prims, float ix, float iy, float iz, float o_x,
+                                         float o_y, float o_z, float lim, int live_i)
+{
+    const bool live = live_i != 0;
+    const unsigned long long lm = __ballot(live);
+    if (lm == 0ull) return 0;
+    const int lane = threadIdx.x & 63;
+    // reciprocal-direction interval of the live lanes per axis
+    const float ilx = wave_min_f(live ? ix : INFINITY), ihx = wave_max_f(live ? ix : -INFINITY);
+    const float ily = wave_min_f(live ? iy : INFINITY), ihy = wave_max_f(live ? iy : -INFINITY);
+    const float ilz = wave_min_f(live ? iz : INFINITY), ihz = wave_max_f(live ? iz : -INFINITY);
+    // nothing beyond the farthest "best so far" (hits on the primitives outside the tree) or the range matters
+    const float far = wave_max_f(live ? lim : 0.f);
+    // the common origin
+    const int src = __ffsll((long long)lm) - 1;
+    const float ox = __shfl(o_x, src, 64), oy = __shfl(o_y, src, 64), oz = __shfl(o_z, src, 64);
+    // an axis constrains when all reciprocals are finite and of one sign
+    const bool px = ilx > 0.f, nx = ihx < 0.f, cx = (px || nx) && fabsf(ilx) < 1e37f && fabsf(ihx) < 1e37f;
+    const bool py = ily > 0.f, ny = ihy < 0.f, cy = (py || ny) && fabsf(ily) < 1e37f && fabsf(ihy) < 1e37f;
+    const bool pz = ilz > 0.f, nz = ihz < 0.f, cz = (pz || nz) && fabsf(ilz) < 1e37f && fabsf(ihz) < 1e37f;
+    int n_front = 1, n_cand = 0;   // wave-uniform
+    if (lane == 0) *beam_slot(0) = 0;
+    wave_lds_fence_();
+    const int slot = lane >> 2, c = lane & 3;
+    for (int guard = n_prims + 8; n_front > 0 && guard > 0; --guard) {
+        const int take = n_front < 16 ? n_front : 16;
+        const int node = slot < take ? *beam_slot(n_front - 1 - slot) : -1;
+        n_front -= take;
+        bool hit = false;
+        int code = 0;
+        if (node >= 0) {
+            const float* nb = (const float*)(bvh4 + 8 * (size_t)node) + c;
+            const float lox = nb[0], loy = nb[4], loz = nb[8], hix = nb[12], hiy = nb[16], hiz = nb[20];
+            code = __float_as_int(nb[24]);
+            float tn = 0.f, tf = far;
+#define VRT_BEAM_AXIS(CON, POS, LO, HI, O, IL, IH)                                          \
+            if (CON) {                                                                      \
+                const float sn = (POS ? LO : HI) - O, sf = (POS ? HI : LO) - O;             \
+                tn = fmaxf(tn, fminf(sn * IL, sn * IH));                                    \
+                tf = fminf(tf, fmaxf(sf * IL, sf * IH));                                    \
+            } else if (!(LO <= HI)) tf = -INFINITY;   /* an unused child slot */
+            VRT_BEAM_AXIS(cx, px, lox, hix, ox, ilx, ihx)
+            VRT_BEAM_AXIS(cy, py, loy, hiy, oy, ily, ihy)
+            VRT_BEAM_AXIS(cz, pz, loz, hiz, oz, ilz, ihz)
+#undef VRT_BEAM_AXIS
+            hit = tn <= tf * 1.00001f + 1e-6f;
+        }
+        const bool inner = hit && code >= 0, leaf = hit && code < 0;
+        const unsigned long long mi = __ballot(inner), ml = __ballot(leaf);
+        if (n_front + __popcll(mi) > VRT_BEAM_FRONT || n_cand + __popcll(ml) > VRT_BEAM_CAND) return -1;
+        wave_lds_fence_();   // the frontier entries of this step have been read
+        if (inner) *beam_slot(n_front + __builtin_amdgcn_mbcnt_hi((unsigned)(mi >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mi, 0u))) = code;
+        if (leaf) *beam_slot(VRT_BEAM_FRONT + n_cand + __builtin_amdgcn_mbcnt_hi((unsigned)(ml >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ml, 0u))) = ~code;
+        n_front += __popcll(mi); n_cand += __popcll(ml);
+        wave_lds_fence_();
+    }
+    return n_front > 0 ? -1 : n_cand;
+}
+
+__device__ __forceinline__ bool intersect_bvh4_beam(const DevScene& S, Trav& T, bool live)
+{
+    const int n_cand = __builtin_amdgcn_readfirstlane(
+        beam_collect(S.bvh4, S.n_prims, T.inv.x, T.inv.y, T.inv.z, T.o.x, T.o.y, T.o.z, trav_limit(T), live ? 1 : 0));
+    if (n_cand < 0) return false;
+    for (int k = 0; k < n_cand; ++k) {
+        const int id = __builtin_amdgcn_readfirstlane(*beam_slot(VRT_BEAM_FRONT + k));
+        count_lanes(S, 7, live);
+        if (live && id != T.skip) test_prim(S, id, T.o, T.d, T.maxd, T.best);
+    }
+    return true;
+}
+
+// Closest hit of the camera rays of a wave (tree scenes): every lane of the wave calls, cast = this
+// lane has a ray.  beam: try the candidate collection above first.
+__device__ __forceinline__ Hit intersect_primary_bvh(const DevScene& S, f3 o, f3 d, float maxd, bool cast, bool packet,
+                                                     bool beam)
+{
+    // the beam works on a traversal record of its own: sharing the one of the ordinary traversal
+    // below cost that traversal 10 % (register allocation)
+    if (VRT_BEAM && beam) {
+        Trav T;
+        trav_begin(T, o, d, maxd, INFINITY, -1);
+        if (cast) trav_big(S, T, false);
+        if (intersect_bvh4_beam(S, T, cast)) return T.best;
+    }
+    Hit h; h.prim = -1; h.t = INFINITY; h.aux = 0;
+    if (cast) h = intersect_bvh4(S, o, d, maxd, INFINITY, -1, false, packet);
+    return h;
+}
 
 // ------------------------------------------------------------------ four lanes per ray
 //
@@ -869,14 +1048,14 @@ __device__ __forceinline__ void hit_geometry(const DevScene& S, Hit h, f3 o, f3 
 {
     point = o + d * h.t;
     if (h.prim < S.n_sph) {
-        normal = normalize3(point - xyz(S.sph[h.prim]));
+        normal = normalize3(point - xyz(ldc(S.sph + h.prim)));
     } else if (h.prim < S.n_sph + S.n_box) {
-        float4 a = S.box[4 * (h.prim - S.n_sph) + 1 + (h.aux & 3)];
+        float4 a = ldc(S.box + (4 * (h.prim - S.n_sph) + 1 + (h.aux & 3)));
         float s = (h.aux & 4) ? 1.f : -1.f;
         normal = xyz(a) * s;
     } else {
         const float4* tr = S.tri + 3 * (size_t)(h.prim - S.n_sph - S.n_box);
-        normal = normalize3(cross3(xyz(tr[1]), xyz(tr[2])));
+        normal = normalize3(cross3(xyz(ldc(tr + 1)), xyz(ldc(tr + 2))));
     }
 }
 
@@ -1064,7 +1243,7 @@ __device__ __forceinline__ f3 phong_shade(const DevScene& S, const DevParams& P,
     f3 wo = -raydir;
     f3 L = (cd * ka) * ambient_L<BVH, RECORD>(S, P, point, n, prim, depth, C, R, occ);
     for (int i = 0; i < S.n_lights; ++i) {
-        const DevLight& l = S.lights[i];
+        const DevLight l = ldc(S.lights + i);
         f3 lp = mk3(l.vx, l.vy, l.vz);
         f3 wi;
         if (l.type == VRT_LIGHT_POINT) {
@@ -1218,7 +1397,7 @@ __device__ __forceinline__ void shade_hit(const DevScene& S, const DevParams& P,
 {
     f3 point, n;
     hit_geometry(S, h, o, d, point, n);
-    const int mi = S.prim_mat[h.prim];
+    const int mi = ldc(S.prim_mat + h.prim);
     if (S.mat_tex) {   // a textured material returns its texel unshaded and ends the path
         const int tx = S.mat_tex[mi];
         if (tx >= 0) {
@@ -1227,7 +1406,7 @@ __device__ __forceinline__ void shade_hit(const DevScene& S, const DevParams& P,
             return;
         }
     }
-    float4 m = S.mat[mi];
+    float4 m = ldc(S.mat + mi);
     int mtype = __float_as_int(m.w);
     f3 cd = mk3(m.x, m.y, m.z);
     const vrt_shading& sh = S.sh;
@@ -1367,21 +1546,25 @@ __device__ __forceinline__ f3 trace_path(const DevScene& S, const DevParams& P, 
 // of the offset table or null.
 template <bool BVH, bool RECORD, bool TWOCHILD>
 __device__ __forceinline__ f3 trace_sample_dev(const DevScene& S, const DevCam& cam, const DevParams& P, f3 raw,
-                                               const float2* off, int i, int& first_prim, Counters& C, Recorder& R)
+                                               const float2* off, int i, int& first_prim, Counters& C, Recorder& R,
+                                               bool live = true, bool wave = false)
 {
+    // wave: all 64 lanes of the wave are here (live tells which hold a sample), so the camera rays
+    // can be traced with the wave-cooperative forms
     f3 O = mk3(cam.ox, cam.oy, cam.oz);
     float ox = 0.f, oy = 0.f;
-    if (off) { float2 q = off[i]; ox = q.x; oy = q.y; }
+    if (off && live) { float2 q = off[i]; ox = q.x; oy = q.y; }
     f3 d = normalize3(mk3(raw.x + ox, raw.y + oy, raw.z));
     R.sample = i;
     Hit first; first.prim = -1; first.t = INFINITY; first.aux = 0;
-    if (!is_zero3(d)) {
-        // one closest-hit query answers both the any-hit pre-check (RayTracerUnity.cs:582)
-        // and the primary TraceRay (:584); they are counted as the two queries they replace
-        VRT_COUNT(C, precheck, VRT_RAY_PRECHECK);
-        first = intersect<BVH, false, true>(S, O, d, P.range, -1, INFINITY, BVH && P.packet);
-    }
+    const bool cast = live && !is_zero3(d);
+    // one closest-hit query answers both the any-hit pre-check (RayTracerUnity.cs:582)
+    // and the primary TraceRay (:584); they are counted as the two queries they replace
+    if (cast) VRT_COUNT(C, precheck, VRT_RAY_PRECHECK);
+    if (BVH && wave) first = intersect_primary_bvh(S, O, d, P.range, cast, P.packet != 0, P.beam != 0);
+    else if (cast) first = intersect<BVH, false, true>(S, O, d, P.range, -1, INFINITY, BVH && P.packet);
     first_prim = first.prim;
+    if (!live) return mk3(0.f, 0.f, 0.f);
     if (first.prim >= 0) {
         VRT_COUNT(C, primary, VRT_RAY_PRIMARY);
         record_seg<RECORD>(R, O, d, first, VRT_RAY_PRIMARY, 0, P.range);
