@@ -108,7 +108,7 @@ extern "C" int vrt_set_option(vrt_ctx* c, const char* name, long long value)
     else if (n == "stack_cap") { if (value < 0 || value > VRT_TRAV_STACK) return fail(c, VRT_ERR_INVALID, "stack_cap: 0..VRT_TRAV_STACK"); o.stack_cap = (int)value; }
     else if (n == "quad_max") { if (value < -1 || value > 64) return fail(c, VRT_ERR_INVALID, "quad_max: -1..64"); o.quad_max = (int)value; }
     else if (n == "fail_after_build") o.fail_after_build = value != 0;
-    else if (n == "beam") { if (value < -1 || value > 1) return fail(c, VRT_ERR_INVALID, "beam: -1, 0 or 1"); o.beam = (int)value; }
+    else if (n == "beam") { if (value < -1 || value > 2) return fail(c, VRT_ERR_INVALID, "beam: -1, 0, 1 or 2"); o.beam = (int)value; }
     else if (n == "packet") { if (value < -1 || value > 2) return fail(c, VRT_ERR_INVALID, "packet: -1, 0, 1 or 2"); o.packet = (int)value; }
     else return fail(c, VRT_ERR_INVALID, "unknown option " + n);
     if (c->multi) return vrt_multi_set_option(c, name, value);
@@ -702,7 +702,7 @@ static int check_params(vrt_ctx* c, const vrt_params* p, DevParams* out)
     // pixel on the 10k-sphere frame, +6 % at 4 lanes per pixel on the 1M-triangle frame).
     P.packet = c->opt.packet >= 0 ? c->opt.packet : (P.sample_shift >= 2 ? 1 : 0);
     P.quad_max = c->opt.quad_max >= 0 ? c->opt.quad_max : 16;
-    P.beam = c->opt.beam >= 0 ? c->opt.beam : (P.sample_shift >= 4 ? 1 : 0);
+    P.beam = c->opt.beam >= 0 ? c->opt.beam : 1;
     P.general = two_children(c, p) ? 1 : 0;
     P.offsets = nullptr;
     return VRT_OK;

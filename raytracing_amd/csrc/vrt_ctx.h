@@ -24,7 +24,7 @@ struct VrtOptions {
     int collapse_parity = 0;    // 1: collapse every second level instead of by surface area
     int no_big = 0;             // 1: scene-sized primitives stay in the tree
     int packet = -1;            // tree scenes: wave-uniform traversal for the rays of one pixel group; -1 = chosen from spp
-    int beam = -1;              // tree scenes, megakernel: camera rays of a wave collect their candidate leaves together; -1 = chosen from the lanes per pixel
+    int beam = -1;              // tree scenes, megakernel: 1 = the camera rays of a wave, and the occlusion rays of their hits, collect their candidate leaves together; 2 = camera rays only; -1 = library default (1)
     int quad_max = -1;          // tree scenes: waves with at most this many queries trace them four lanes per ray; -1 = library default
     int slab_fma = 1;           // tree scenes: fused box test where the scene lies near enough to the origin for it (0: never)
     int stack_cap = 0;          // tests: traversal-stack entries per lane (0 = all the kernels have), forces the stackless finish

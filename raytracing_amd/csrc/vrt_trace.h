@@ -758,10 +758,10 @@ __device__ __forceinline__ bool intersect_bvh4_packet(const DevScene& S, Trav& T
 #define VRT_BEAM 1
 #endif
 #ifndef VRT_BEAM_FRONT
-#define VRT_BEAM_FRONT 80
+#define VRT_BEAM_FRONT 160
 #endif
 #ifndef VRT_BEAM_CAND
-#define VRT_BEAM_CAND 48
+#define VRT_BEAM_CAND 96
 #endif
 // Frontier and candidate list live in the wave's columns of the traversal stack, which is idle
 // while the beam runs: slot k = row k / 64, column k % 64 of the wave.
@@ -793,7 +793,7 @@ __device__ __forceinline__ float wave_max_f(float v)
 // Takes what it needs by value (a reference to the scene would force the scene into memory).
 // Returns the number of candidates, now in beam_slot(VRT_BEAM_FRONT + k), or -1 on overflow.
 __device__ __noinline__ int beam_collect(const float4* bvh4, int n_prims, float ix, float iy, float iz, float o_x,
-                                         float o_y, float o_z, float lim, int live_i)
+                                         float o_y, float o_z, float lim, int live_i, int one_origin)
 {
     const bool live = live_i != 0;
     const unsigned long long lm = __ballot(live);
@@ -803,11 +803,18 @@ __device__ __noinline__ int beam_collect(const float4* bvh4, int n_prims, float 
     const float ilx = wave_min_f(live ? ix : INFINITY), ihx = wave_max_f(live ? ix : -INFINITY);
     const float ily = wave_min_f(live ? iy : INFINITY), ihy = wave_max_f(live ? iy : -INFINITY);
     const float ilz = wave_min_f(live ? iz : INFINITY), ihz = wave_max_f(live ? iz : -INFINITY);
-    // nothing beyond the farthest "best so far" (hits on the primitives outside the tree) or the range matters
+    // nothing beyond the farthest limit of a lane (its range, its "nearer than" bound, a hit it has) matters
     const float far = wave_max_f(live ? lim : 0.f);
-    // the common origin
-    const int src = __ffsll((long long)lm) - 1;
-    const float ox = __shfl(o_x, src, 64), oy = __shfl(o_y, src, 64), oz = __shfl(o_z, src, 64);
+    // origin interval: one point for camera rays, the lanes' hit points for occlusion rays
+    float olx, ohx, oly, ohy, olz, ohz;
+    if (one_origin) {
+        const int src = __ffsll((long long)lm) - 1;
+        olx = ohx = __shfl(o_x, src, 64); oly = ohy = __shfl(o_y, src, 64); olz = ohz = __shfl(o_z, src, 64);
+    } else {
+        olx = wave_min_f(live ? o_x : INFINITY); ohx = wave_max_f(live ? o_x : -INFINITY);
+        oly = wave_min_f(live ? o_y : INFINITY); ohy = wave_max_f(live ? o_y : -INFINITY);
+        olz = wave_min_f(live ? o_z : INFINITY); ohz = wave_max_f(live ? o_z : -INFINITY);
+    }
     // an axis constrains when all reciprocals are finite and of one sign
     const bool px = ilx > 0.f, nx = ihx < 0.f, cx = (px || nx) && fabsf(ilx) < 1e37f && fabsf(ihx) < 1e37f;
     const bool py = ily > 0.f, ny = ihy < 0.f, cy = (py || ny) && fabsf(ily) < 1e37f && fabsf(ihy) < 1e37f;
@@ -823,19 +830,22 @@ __device__ __noinline__ int beam_collect(const float4* bvh4, int n_prims, float 
         bool hit = false;
         int code = 0;
         if (node >= 0) {
-            const float* nb = (const float*)(bvh4 + 8 * (size_t)node) + c;
+            const VRT_CONST_AS float* nb = (const VRT_CONST_AS float*)(bvh4 + 8 * (size_t)node) + c;
             const float lox = nb[0], loy = nb[4], loz = nb[8], hix = nb[12], hiy = nb[16], hiz = nb[20];
             code = __float_as_int(nb[24]);
             float tn = 0.f, tf = far;
-#define VRT_BEAM_AXIS(CON, POS, LO, HI, O, IL, IH)                                          \
+            // entry distance (plane - origin) * inv is smallest, over origins and reciprocals, for the
+            // largest origin when inv > 0 and the smallest when inv < 0; the exit distance is largest
+            // for the other one
+#define VRT_BEAM_AXIS(CON, POS, LO, HI, OL, OH, IL, IH)                                     \
             if (CON) {                                                                      \
-                const float sn = (POS ? LO : HI) - O, sf = (POS ? HI : LO) - O;             \
+                const float sn = POS ? LO - OH : HI - OL, sf = POS ? HI - OL : LO - OH;     \
                 tn = fmaxf(tn, fminf(sn * IL, sn * IH));                                    \
                 tf = fminf(tf, fmaxf(sf * IL, sf * IH));                                    \
             } else if (!(LO <= HI)) tf = -INFINITY;   /* an unused child slot */
-            VRT_BEAM_AXIS(cx, px, lox, hix, ox, ilx, ihx)
-            VRT_BEAM_AXIS(cy, py, loy, hiy, oy, ily, ihy)
-            VRT_BEAM_AXIS(cz, pz, loz, hiz, oz, ilz, ihz)
+            VRT_BEAM_AXIS(cx, px, lox, hix, olx, ohx, ilx, ihx)
+            VRT_BEAM_AXIS(cy, py, loy, hiy, oly, ohy, ily, ihy)
+            VRT_BEAM_AXIS(cz, pz, loz, hiz, olz, ohz, ilz, ihz)
 #undef VRT_BEAM_AXIS
             hit = tn <= tf * 1.00001f + 1e-6f;
         }
@@ -854,7 +864,7 @@ __device__ __noinline__ int beam_collect(const float4* bvh4, int n_prims, float 
 __device__ __forceinline__ bool intersect_bvh4_beam(const DevScene& S, Trav& T, bool live)
 {
     const int n_cand = __builtin_amdgcn_readfirstlane(
-        beam_collect(S.bvh4, S.n_prims, T.inv.x, T.inv.y, T.inv.z, T.o.x, T.o.y, T.o.z, trav_limit(T), live ? 1 : 0));
+        beam_collect(S.bvh4, S.n_prims, T.inv.x, T.inv.y, T.inv.z, T.o.x, T.o.y, T.o.z, trav_limit(T), live ? 1 : 0, 1));
     if (n_cand < 0) return false;
     for (int k = 0; k < n_cand; ++k) {
         const int id = __builtin_amdgcn_readfirstlane(*beam_slot(VRT_BEAM_FRONT + k));
@@ -880,6 +890,40 @@ __device__ __forceinline__ Hit intersect_primary_bvh(const DevScene& S, f3 o, f3
     Hit h; h.prim = -1; h.t = INFINITY; h.aux = 0;
     if (cast) h = intersect_bvh4(S, o, d, maxd, INFINITY, -1, false, packet);
     return h;
+}
+
+// Occlusion queries a wave asks together (the ambient-occlusion rays, or the shadow rays towards
+// one light, of the hits of its camera rays): is there a collider nearer than tlim?  Every lane
+// of the wave calls, want = this lane has a query.  The beam takes the lanes' origins as an
+// interval as well; an any-hit query needs no order among the candidates.
+__device__ __forceinline__ bool occluded_wave(const DevScene& S, bool want, f3 o, f3 d, float maxd, float tlim, int skip,
+                                              bool packet)
+{
+    Trav T;
+    trav_begin(T, o, d, maxd, tlim, skip);
+    const bool live = want && !is_zero3(d);
+    bool found = false;
+    if (live) found = trav_big(S, T, true);
+    const bool need = live && !found;
+    const int n_cand = __builtin_amdgcn_readfirstlane(
+        beam_collect(S.bvh4, S.n_prims, T.inv.x, T.inv.y, T.inv.z, o.x, o.y, o.z, T.lim0, need ? 1 : 0, 0));
+    if (n_cand < 0) {
+        if (need) found = intersect_bvh4(S, o, d, maxd, tlim, skip, true, packet).prim >= 0;
+        return found;
+    }
+    for (int k = 0; k < n_cand; ++k) {
+        if (!__any(need && !found)) break;
+        const int id = __builtin_amdgcn_readfirstlane(*beam_slot(VRT_BEAM_FRONT + k));
+        count_lanes(S, 7, need && !found);
+        if (need && !found && id != skip) {
+            test_prim(S, id, T.o, T.d, T.maxd, T.best);
+            if (T.best.prim >= 0) {
+                if (T.best.t < tlim) found = true;
+                else { T.best.prim = -1; T.best.t = INFINITY; }
+            }
+        }
+    }
+    return found;
 }
 
 // ------------------------------------------------------------------ four lanes per ray
@@ -1195,6 +1239,34 @@ struct OccInline {
     }
 };
 
+// Provider of the answers gathered in a flag word (bit k = query k is occluded).
+struct OccBits {
+    static constexpr bool counts = false;
+    unsigned bits;
+    template <bool BVH>
+    __device__ __forceinline__ bool occluded(const DevScene&, int k, f3, f3, float, float, int) { return (bits >> k) & 1u; }
+};
+
+// Provider of a shading pass whose only purpose is to find out which queries the hit asks: the
+// ambient-occlusion ray (k = 0) and the shadow ray towards the first light (k = 1) are kept for the
+// wave to trace together (occluded_wave), those towards further lights are traced on the spot and
+// their answers noted in `bits`.  The pass counts the rays; its shading result is discarded.
+struct OccCapture {
+    static constexpr bool counts = true;
+    bool packet = false;
+    unsigned has = 0, bits = 0;
+    f3 d0, d1;
+    float tlim0 = 0.f, tlim1 = 0.f, maxd0 = 0.f, maxd1 = 0.f;
+    template <bool BVH>
+    __device__ __forceinline__ bool occluded(const DevScene& S, int k, f3 o, f3 d, float maxd, float tlim, int skip)
+    {
+        if (k == 0) { has |= 1u; d0 = d; tlim0 = tlim; maxd0 = maxd; }
+        else if (k == 1) { has |= 2u; d1 = d; tlim1 = tlim; maxd1 = maxd; }
+        else if (intersect<BVH, true>(S, o, d, maxd, skip, tlim, packet).prim >= 0) bits |= 1u << k;
+        return false;
+    }
+};
+
 // Light/AmbientOccluder.cs:56-85.  The reference builds u and v with Mathf.Pow of the normal's
 // components and shoots sp.x*u + sp.y*v + sp.z*w with the hemisphere sample sp = (0,0,1) (its
 // multi-jittered table is all zeros, Sampler/MultiJitteredSampler.cs:23-27,39).  A negative base
@@ -1491,32 +1563,37 @@ struct PendingRay { f3 o, d, T; int depth, skip, kind; };
 // sum(throughput * direct term) instead of unwinding a recursion; the second child of a
 // refracting hit waits on a bounded per-lane stack.
 template <bool BVH, bool RECORD, bool TWOCHILD>
+// shaded: the first hit has been shaded already (its Bounce), the loop starts at its children.
 __device__ __forceinline__ f3 trace_path(const DevScene& S, const DevParams& P, f3 o, f3 d, Hit first,
-                                         Counters& C, Recorder& R, int depth0 = 0)
+                                         Counters& C, Recorder& R, int depth0 = 0, const Bounce* shaded = nullptr)
 {
     f3 L = mk3(0.f, 0.f, 0.f);
     f3 T = mk3(1.f, 1.f, 1.f);
     int depth = depth0, skip = -1, kind = VRT_RAY_PRIMARY;
     Hit h = first;
     bool have_first = true;
+    bool have_B = shaded != nullptr;
+    Bounce B;
+    if (have_B) B = *shaded;
     PendingRay stack[TWOCHILD ? VRT_MAX_DEPTH + 2 : 1];
     int sp = 0;
     for (;;) {
-        if (!have_first) {
-            h.prim = -1; h.t = INFINITY; h.aux = 0;
-            if (!is_zero3(d)) {
-                if (kind == VRT_RAY_REFLECT) VRT_COUNT(C, reflect, VRT_RAY_REFLECT); else VRT_COUNT(C, transmit, VRT_RAY_TRANSMIT);
-                h = intersect<BVH, false>(S, o, d, P.range, skip, INFINITY, BVH && P.packet == 2);
-                record_seg<RECORD>(R, o, d, h, kind, depth, P.range);
+        if (!have_B) {
+            if (!have_first) {
+                h.prim = -1; h.t = INFINITY; h.aux = 0;
+                if (!is_zero3(d)) {
+                    if (kind == VRT_RAY_REFLECT) VRT_COUNT(C, reflect, VRT_RAY_REFLECT); else VRT_COUNT(C, transmit, VRT_RAY_TRANSMIT);
+                    h = intersect<BVH, false>(S, o, d, P.range, skip, INFINITY, BVH && P.packet == 2);
+                    record_seg<RECORD>(R, o, d, h, kind, depth, P.range);
+                }
             }
+            if (h.prim < 0) L = L + T * sky_color(d);
+            else { shade_hit<BVH, RECORD>(S, P, h, o, d, depth, C, R, B); have_B = true; }
         }
         have_first = false;
         bool cont = false;
-        if (h.prim < 0) {
-            L = L + T * sky_color(d);
-        } else {
-            Bounce B;
-            shade_hit<BVH, RECORD>(S, P, h, o, d, depth, C, R, B);
+        if (have_B) {
+            have_B = false;
             L = L + T * B.A;
             if (B.n_child > 0 && depth + 1 <= P.max_depth) {
                 if constexpr (TWOCHILD) if (B.n_child == 2 && sp < VRT_MAX_DEPTH + 2) {
@@ -1564,6 +1641,35 @@ __device__ __forceinline__ f3 trace_sample_dev(const DevScene& S, const DevCam& 
     if (BVH && wave) first = intersect_primary_bvh(S, O, d, P.range, cast, P.packet != 0, P.beam != 0);
     else if (cast) first = intersect<BVH, false, true>(S, O, d, P.range, -1, INFINITY, BVH && P.packet);
     first_prim = first.prim;
+    if constexpr (BVH && !RECORD) {
+        if (wave && P.beam == 1) {
+            // The hits' ambient-occlusion rays and their shadow rays towards the first light are
+            // traced by the wave together: one shading pass only asks which queries there are (and
+            // counts them), the wave answers them, a second pass shades with the answers.
+            const bool hit = live && first.prim >= 0;
+            OccCapture cap;
+            cap.packet = P.packet != 0;
+            f3 point = O;
+            if (hit) {
+                VRT_COUNT(C, primary, VRT_RAY_PRIMARY);
+                Bounce unused;
+                shade_hit<BVH, false>(S, P, first, O, d, 0, C, R, unused, cap);
+                point = unused.o;
+            }
+            unsigned bits = cap.bits;
+            if (occluded_wave(S, hit && (cap.has & 1u), point, cap.d0, cap.maxd0, cap.tlim0, first.prim, P.packet != 0)) bits |= 1u;
+            if (occluded_wave(S, hit && (cap.has & 2u), point, cap.d1, cap.maxd1, cap.tlim1, first.prim, P.packet != 0)) bits |= 2u;
+            if (!live) return mk3(0.f, 0.f, 0.f);
+            if (hit) {
+                OccBits answers; answers.bits = bits;
+                Bounce B;
+                shade_hit<BVH, false>(S, P, first, O, d, 0, C, R, B, answers);
+                return trace_path<BVH, false, TWOCHILD>(S, P, O, d, first, C, R, 0, &B);
+            }
+            if (P.flags & VRT_FIX_PRIMARY_SKY) return sky_color(d);
+            return mk3(0.f, 0.f, 0.f);
+        }
+    }
     if (!live) return mk3(0.f, 0.f, 0.f);
     if (first.prim >= 0) {
         VRT_COUNT(C, primary, VRT_RAY_PRIMARY);

@@ -100,3 +100,17 @@ def test_wavefront_tiles_compact(vrt_ctx):
                                      compact_rows=True), rgba=out, hit=hit)
             assert np.array_equal(out, whole[rows], equal_nan=True)
             assert np.array_equal(hit, whole_hit[rows])
+
+
+def test_shadow_rays_end_after_30_units(vrt_ctx, oracle_mod):
+    """The reference casts its shadow rays with a fixed range of 30 units (PointLight.cs:23-51), so a
+    collider farther than that from the shaded point never shadows it, however far the light is.
+    A low, distant light sends the shadow rays of the whole sphere field horizontally through it:
+    most have colliders both nearer and farther than 30 units.  Wave-cooperative occlusion queries
+    (the default for the hits of camera rays) must keep each query's own range."""
+    scene = ra.random_spheres_scene(n=1500, seed=21)
+    scene.lights["vec"][0] = (100.0, 3.0, 5.0)
+    cam = ra.random_spheres_camera(160, 90)
+    offs = host.sampler_table(abi.VRT_SAMPLER_JITTERED, 4, 3, 0.02, 0.02, seed=5)
+    rgba, hit, st = _check(vrt_ctx, oracle_mod, scene, cam, ra.Params(spp=4, offsets=offs, seed=3, max_depth=3, rng=200.0))
+    assert st.rays[abi.VRT_RAY_SHADOW] > 10000
