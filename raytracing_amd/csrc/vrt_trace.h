@@ -793,7 +793,8 @@ __device__ __forceinline__ float wave_max_f(float v)
 // Takes what it needs by value (a reference to the scene would force the scene into memory).
 // Returns the number of candidates, now in beam_slot(VRT_BEAM_FRONT + k), or -1 on overflow.
 __device__ __noinline__ int beam_collect(const float4* bvh4, int n_prims, float ix, float iy, float iz, float o_x,
-                                         float o_y, float o_z, float lim, int live_i, int one_origin)
+                                         float o_y, float o_z, float lim, int live_i, int one_origin,
+                                         unsigned long long* dbg)
 {
     const bool live = live_i != 0;
     const unsigned long long lm = __ballot(live);
@@ -829,6 +830,13 @@ __device__ __noinline__ int beam_collect(const float4* bvh4, int n_prims, float 
         n_front -= take;
         bool hit = false;
         int code = 0;
+#if VRT_COUNT_NODES   // a frontier node counts once: its four boxes are tested once, by four lanes
+        {
+            const unsigned long long m = __ballot(node >= 0 && c == 0);
+            if (m && lane == __ffsll((long long)m) - 1)
+                atomicAdd(&dbg[(blockIdx.x % VRT_CTR_SLOTS) * VRT_CTR_STRIDE + 6], (unsigned long long)__popcll(m));
+        }
+#endif
         if (node >= 0) {
             const VRT_CONST_AS float* nb = (const VRT_CONST_AS float*)(bvh4 + 8 * (size_t)node) + c;
             const float lox = nb[0], loy = nb[4], loz = nb[8], hix = nb[12], hiy = nb[16], hiz = nb[20];
@@ -864,7 +872,7 @@ __device__ __noinline__ int beam_collect(const float4* bvh4, int n_prims, float 
 __device__ __forceinline__ bool intersect_bvh4_beam(const DevScene& S, Trav& T, bool live)
 {
     const int n_cand = __builtin_amdgcn_readfirstlane(
-        beam_collect(S.bvh4, S.n_prims, T.inv.x, T.inv.y, T.inv.z, T.o.x, T.o.y, T.o.z, trav_limit(T), live ? 1 : 0, 1));
+        beam_collect(S.bvh4, S.n_prims, T.inv.x, T.inv.y, T.inv.z, T.o.x, T.o.y, T.o.z, trav_limit(T), live ? 1 : 0, 1, S.dbg));
     if (n_cand < 0) return false;
     for (int k = 0; k < n_cand; ++k) {
         const int id = __builtin_amdgcn_readfirstlane(*beam_slot(VRT_BEAM_FRONT + k));
@@ -906,7 +914,7 @@ __device__ __forceinline__ bool occluded_wave(const DevScene& S, bool want, f3 o
     if (live) found = trav_big(S, T, true);
     const bool need = live && !found;
     const int n_cand = __builtin_amdgcn_readfirstlane(
-        beam_collect(S.bvh4, S.n_prims, T.inv.x, T.inv.y, T.inv.z, o.x, o.y, o.z, T.lim0, need ? 1 : 0, 0));
+        beam_collect(S.bvh4, S.n_prims, T.inv.x, T.inv.y, T.inv.z, o.x, o.y, o.z, T.lim0, need ? 1 : 0, 0, S.dbg));
     if (n_cand < 0) {
         if (need) found = intersect_bvh4(S, o, d, maxd, tlim, skip, true, packet).prim >= 0;
         return found;
