@@ -269,8 +269,9 @@ const char* vrt_last_error(vrt_ctx* ctx);
  * on the first GPU.  The non-blocking and device-pointer calls are not offered on such a context. */
 int vrt_create_multi(int n_gpus, const int* devices, vrt_ctx** out);
 
-/* Study and test knobs by name ("sample_shift", "packet", "wf_defer", "wf_refill", "wf_max_slots",
- * "wf_any_cap", "builder", "collapse_parity", "no_big", "xcd_remap", "block_compact"); none changes a result.
+/* Study and test knobs by name ("sample_shift", "packet", "beam", "slab_fma", "quad_max", "stack_cap",
+ * "wf_defer", "wf_refill", "wf_max_slots", "wf_any_cap", "wf_queue_cap", "builder", "collapse_parity",
+ * "no_big", "xcd_remap", "block_compact", "fail_after_build"); none changes a result.
  * builder / collapse_parity / no_big take effect at the next vrt_set_scene.  No counterpart in
  * the reference. */
 int vrt_set_option(vrt_ctx* ctx, const char* name, long long value);
