@@ -296,3 +296,31 @@ def test_scene_far_from_the_origin_keeps_the_plain_box_test(vrt_ctx, oracle_mod)
     assert np.array_equal(got_hit, ref_hit)
     assert np.array_equal(np.array(st.rays[:], np.uint64), ref_rays)
     assert np.abs(got - ref).max() <= 1.0 / 255.0
+
+
+@pytest.mark.parametrize("which", ["spheres", "mesh"])
+@pytest.mark.parametrize("spp", [1, 4, 16])
+def test_beam_gives_the_same_frame(vrt_ctx, vrt_opts, which, spp):
+    """The camera rays of a wave, and the ambient-occlusion and first-light shadow rays of their
+    hits, collect their candidate leaves together (option beam: 1 both, 2 camera rays only, 0 off).
+    The candidates are a superset of what each ray's own traversal visits and hits are ranked by
+    (t, id), so frames, hit ids and ray counts must not change, for every lane split (8x8-pixel
+    waves at 1 sample per pixel, where most beams are too wide and are abandoned, down to 2x2
+    pixels x 16 samples), on a frame whose size leaves partly filled waves at two edges, with one
+    and with two child rays per hit."""
+    if which == "spheres":
+        scene, cam, rng = ra.random_spheres_scene(n=3000, seed=11), ra.random_spheres_camera(131, 75), 200.0
+    else:
+        scene, cam, rng = ra.tessellated_mesh_scene(quads=60), ra.tessellated_mesh_camera(131, 75), 100.0
+    offs = host.sampler_table(abi.VRT_SAMPLER_JITTERED, spp, 3, 0.02, 0.02, seed=5) if spp > 1 else None
+    vrt_ctx.set_scene(scene)
+    vrt_ctx.set_camera(cam)
+    for flags in (0, abi.VRT_FIX_DIELECTRIC):
+        kw = dict(spp=spp, offsets=offs, seed=2, max_depth=4, rng=rng, flags=flags)
+        vrt_opts("beam", 0)
+        ref, ref_hit, ref_st = vrt_ctx.render(ra.Params(**kw))
+        for beam in (2, 1):
+            vrt_opts("beam", beam)
+            got, got_hit, st = vrt_ctx.render(ra.Params(**kw))
+            assert np.array_equal(got, ref, equal_nan=True) and np.array_equal(got_hit, ref_hit), (beam, flags)
+            assert list(st.rays) == list(ref_st.rays), (beam, flags)
