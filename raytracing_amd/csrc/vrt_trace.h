@@ -775,18 +775,30 @@ __device__ __forceinline__ void wave_lds_fence_()
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
+// Minimum / maximum over the 64 lanes of a wave, all of which must be active: six DPP steps in the
+// vector ALU (shifts within rows of 16 lanes, then the row broadcasts of GFX9), the result read
+// from lane 63 into a scalar register.  A lane whose source lies outside its row keeps its value.
+// (The s_nop are the wait states a DPP read needs after a vector write of the same register; the
+// compiler cannot see into the asm to insert them.)
+#define VRT_WAVE_REDUCE(OP)                                                                       \
+    asm("s_nop 1\n\t" OP " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"                   \
+        "s_nop 1\n\t" OP " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"                   \
+        "s_nop 1\n\t" OP " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"                   \
+        "s_nop 1\n\t" OP " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"                   \
+        "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"                \
+        "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"                \
+        "s_nop 1" : "+v"(v))
 __device__ __forceinline__ float wave_min_f(float v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
-    return v;
+    VRT_WAVE_REDUCE("v_min_f32_dpp");
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ float wave_max_f(float v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    VRT_WAVE_REDUCE("v_max_f32_dpp");
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
+#undef VRT_WAVE_REDUCE
 
 // The collection pass.  Not inlined on purpose: compiled into the frame kernel it changed the
 // register allocation of every traversal loop there (10 % on frames that never take the beam).
