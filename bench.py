@@ -119,8 +119,8 @@ def profiled_counters(workload, prefix="r02"):
 def tree_roofline(workload, scene, st, rays, queries, kernel_ms, fb_bytes):
     """What bounds the frame kernel of a scene traced through the 4-wide tree, from what the kernel
     itself incurs: per ray it enters `nodes_per_ray` wide nodes (128 B each, seven 16-byte loads per
-    lane, four slab tests) and tests `prims_per_ray` primitives (measured with a -DVRT_COUNT_NODES=1
-    build, kept in profiles/traversal.json).  Those loads hit the vector L1 (98 %), so they are
+    lane, four slab tests; a frontier node of a wave's beam counts once) and tests `prims_per_ray`
+    primitives (measured with a -DVRT_COUNT_NODES=1 build, kept in profiles/traversal.json).  Those loads hit the vector L1 (98 %), so they are
     priced against the L1 rate, the measured HBM bytes against the HBM rate, and the arithmetic
     against the FP32 vector peak: the vector ALUs are the roof that is closest."""
     trav = None
@@ -153,10 +153,14 @@ def tree_roofline(workload, scene, st, rays, queries, kernel_ms, fb_bytes):
                      "traversal": trav,
                      "l1": {"bytes_per_launch": l1_bytes, "achieved_GBps": l1_bytes / secs / 1e9, "peak_GBps": l1_peak,
                             "frac": l1_bytes / secs / 1e9 / l1_peak},
-                     "note": "arithmetic of the box and primitive tests the rays of this frame need (bookkeeping "
+                     "note": "arithmetic of the box and primitive tests the kernel executes for this frame (bookkeeping "
                              "excluded) against the FP32 vector peak; node and primitive loads against the vector-L1 "
-                             "rate; measured HBM bytes in `traffic`.  `profiled` holds the issue-slot share and lane "
-                             "activity of the committed counter passes"})
+                             "rate; measured HBM bytes in `traffic`.  Camera rays and the occlusion rays of their hits "
+                             "walk the tree once per wave (a frontier node counts once, not once per ray), so fewer "
+                             "box tests are executed per ray than a per-ray traversal needs (4.8 instead of 16.5 nodes "
+                             "on the 10k-sphere frame) and `frac` falls while the frame gets faster; `profiled` holds "
+                             "the issue-slot share and lane activity of the committed counter passes, which is the "
+                             "figure that says how busy the vector ALUs are"})
     else:
         roof.update({"achieved": None, "frac": None, "note": "profiles/traversal.json missing: no per-ray node counts"})
     return roof
