@@ -1275,7 +1275,7 @@ struct OccCapture {
     static constexpr bool counts = true;
     bool packet = false;
     unsigned has = 0, bits = 0;
-    f3 d0, d1;
+    f3 d0 = {0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f};   // zero direction: no query
     float tlim0 = 0.f, tlim1 = 0.f, maxd0 = 0.f, maxd1 = 0.f;
     template <bool BVH>
     __device__ __forceinline__ bool occluded(const DevScene& S, int k, f3 o, f3 d, float maxd, float tlim, int skip)
