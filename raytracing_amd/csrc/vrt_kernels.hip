@@ -25,9 +25,6 @@
 namespace VRT_FORM {
 
 #define VRT_MEGA_THREADS 64
-#ifndef VRT_WAVE_PRIMARY
-#define VRT_WAVE_PRIMARY 1
-#endif
 #ifndef VRT_BVH_WAVES
 #define VRT_BVH_WAVES 4
 #endif
@@ -101,7 +98,7 @@ __global__ __launch_bounds__(VRT_MEGA_THREADS, BVH ? VRT_BVH_WAVES : (SIMPLE ? V
             // the whole wave goes in, so that the camera rays can be traced cooperatively
             const bool live = inside && i < P.spp;
             int fp;
-            c = trace_sample_dev<BVH, false, TWOCHILD>(S, cam, P, raw, off, i, fp, C, R, live, VRT_WAVE_PRIMARY != 0);
+            c = trace_sample_dev<BVH, false, TWOCHILD>(S, cam, P, raw, off, i, fp, C, R, live, true);
             if (live && i == 0) id = fp;
         } else if (inside && i < P.spp) {
             int fp;

@@ -754,9 +754,6 @@ __device__ __forceinline__ bool intersect_bvh4_packet(const DevScene& S, Trav& T
 // frontier steps instead of 16 node steps.  All 64 lanes must call; live = this lane holds a ray.
 // Returns false, with nothing changed, when frontier or candidate list would overflow (a wide
 // beam): the caller then traverses as usual.
-#ifndef VRT_BEAM
-#define VRT_BEAM 1
-#endif
 #ifndef VRT_BEAM_FRONT
 #define VRT_BEAM_FRONT 160
 #endif
@@ -901,7 +898,7 @@ __device__ __forceinline__ Hit intersect_primary_bvh(const DevScene& S, f3 o, f3
 {
     // the beam works on a traversal record of its own: sharing the one of the ordinary traversal
     // below cost that traversal 10 % (register allocation)
-    if (VRT_BEAM && beam) {
+    if (beam) {
         Trav T;
         trav_begin(T, o, d, maxd, INFINITY, -1);
         if (cast) trav_big(S, T, false);
