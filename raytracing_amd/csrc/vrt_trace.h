@@ -829,10 +829,26 @@ __device__ __noinline__ int beam_collect(const float4* bvh4, int n_prims, float 
     const bool px = ilx > 0.f, nx = ihx < 0.f, cx = (px || nx) && fabsf(ilx) < 1e37f && fabsf(ihx) < 1e37f;
     const bool py = ily > 0.f, ny = ihy < 0.f, cy = (py || ny) && fabsf(ily) < 1e37f && fabsf(ihy) < 1e37f;
     const bool pz = ilz > 0.f, nz = ihz < 0.f, cz = (pz || nz) && fabsf(ilz) < 1e37f && fabsf(ihz) < 1e37f;
-    int n_front = 1, n_cand = 0;   // wave-uniform
-    if (lane == 0) *beam_slot(0) = 0;
-    wave_lds_fence_();
+    int n_front = 0, n_cand = 0;   // wave-uniform
     const int slot = lane >> 2, c = lane & 3;
+    {
+        // The first two levels without box tests: the frontier starts with the children of the
+        // root's children (lane 4k+c: child c of the root's child k), which fill one step of 16
+        // nodes; testing the root and then its children first would be two steps that use 4 and
+        // at most 16 lanes.  A leaf among them becomes a candidate untested.
+        int code = VRT_BVH4_EMPTY;
+        if (lane < 16) {
+            const int c1 = ((const VRT_CONST_AS int*)(bvh4 + 6))[slot];
+            if (c1 >= 0) code = ((const VRT_CONST_AS int*)(bvh4 + 8 * (size_t)c1 + 6))[c];
+            else if (c == 0) code = c1;
+        }
+        const bool inner = code >= 0, leaf = code < 0 && code != VRT_BVH4_EMPTY;
+        const unsigned long long mi = __ballot(inner), ml = __ballot(leaf);
+        if (inner) *beam_slot(__builtin_amdgcn_mbcnt_hi((unsigned)(mi >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mi, 0u))) = code;
+        if (leaf) *beam_slot(VRT_BEAM_FRONT + __builtin_amdgcn_mbcnt_hi((unsigned)(ml >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ml, 0u))) = ~code;
+        n_front = __popcll(mi); n_cand = __popcll(ml);
+    }
+    wave_lds_fence_();
     for (int guard = n_prims + 8; n_front > 0 && guard > 0; --guard) {
         const int take = n_front < 16 ? n_front : 16;
         const int node = slot < take ? *beam_slot(n_front - 1 - slot) : -1;
