@@ -6,7 +6,9 @@
 // Closest-hit results do not depend on the tree (candidates are ranked by (t, id)), so the
 // builder only has to be conservative: primitive boxes are padded by a relative 1e-4.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstring>
+#include <vector>
 #include <rocprim/rocprim.hpp>
 
 #include "vrt_launch.h"
@@ -428,10 +430,141 @@ __global__ __launch_bounds__(256) void k_store_parents(int n_inner, const int* _
 
 } // namespace
 
+// ------------------------------------------------------------------ binned SAH build on the host
+//
+// Top-down build by the surface-area heuristic with 16 bins per axis over the primitives'
+// centroids (Wald 2007), one primitive per leaf, for scenes whose tree is built once and traced
+// many times: the padded primitive boxes come from k_prim_bounds, the binary nodes, parent and
+// leaf-parent arrays go back to the device in the layout k_ploc_emit writes, and the 4-wide
+// collapse runs on them as on any other binary tree.  Node 0 is the root (preorder numbering).
+static inline float int_bits_as_float(int v) { float f; memcpy(&f, &v, 4); return f; }
+#ifndef VRT_SAH_BINS
+#define VRT_SAH_BINS 16
+#endif
+struct SahRef { float lo[3], hi[3], c[3]; int id; };
+struct SahBox {
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    void grow(const float* l, const float* h) { for (int k = 0; k < 3; ++k) { lo[k] = fminf(lo[k], l[k]); hi[k] = fmaxf(hi[k], h[k]); } }
+    float area() const
+    {
+        const float x = hi[0] - lo[0], y = hi[1] - lo[1], z = hi[2] - lo[2];
+        return x < 0.f ? 0.f : x * y + y * z + z * x;
+    }
+};
+struct SahBuild {
+    std::vector<SahRef> refs;
+    std::vector<float4> nodes;
+    std::vector<int> parent, leaf_parent;
+    int next = 0;
+
+    // builds refs[b, e); returns the child code and the box
+    int build(int b, int e, int parent_idx, SahBox& box)
+    {
+        if (e - b == 1) {
+            const SahRef& r = refs[b];
+            leaf_parent[r.id] = parent_idx;
+            box.grow(r.lo, r.hi);
+            return ~r.id;
+        }
+        const int idx = next++;
+        parent[idx] = parent_idx;
+        float cl[3] = {INFINITY, INFINITY, INFINITY}, ch[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int i = b; i < e; ++i)
+            for (int k = 0; k < 3; ++k) { cl[k] = fminf(cl[k], refs[i].c[k]); ch[k] = fmaxf(ch[k], refs[i].c[k]); }
+        constexpr int NB = VRT_SAH_BINS;
+        float best = INFINITY;
+        int best_axis = -1, best_bin = 0;
+        for (int k = 0; k < 3; ++k) {
+            const float ext = ch[k] - cl[k];
+            if (!(ext > 0.f)) continue;
+            const float scale = NB / ext;
+            SahBox bins[NB];
+            int cnt[NB] = {0};
+            for (int i = b; i < e; ++i) {
+                int q = (int)((refs[i].c[k] - cl[k]) * scale);
+                q = q < 0 ? 0 : (q >= NB ? NB - 1 : q);
+                bins[q].grow(refs[i].lo, refs[i].hi);
+                cnt[q]++;
+            }
+            float right_area[NB];
+            int right_cnt[NB];
+            SahBox acc;
+            int n_acc = 0;
+            for (int q = NB - 1; q > 0; --q) {
+                if (cnt[q]) acc.grow(bins[q].lo, bins[q].hi);
+                n_acc += cnt[q];
+                right_area[q] = acc.area(); right_cnt[q] = n_acc;
+            }
+            SahBox left;
+            int n_left = 0;
+            for (int q = 0; q < NB - 1; ++q) {
+                if (cnt[q]) left.grow(bins[q].lo, bins[q].hi);
+                n_left += cnt[q];
+                if (n_left == 0 || right_cnt[q + 1] == 0) continue;
+                const float cost = left.area() * n_left + right_area[q + 1] * right_cnt[q + 1];
+                if (cost < best) { best = cost; best_axis = k; best_bin = q; }
+            }
+        }
+        int mid;
+        if (best_axis < 0) {
+            mid = (b + e) / 2;   // all centroids coincide
+        } else {
+            const int k = best_axis;
+            const float scale = NB / (ch[k] - cl[k]);
+            const float base = cl[k];
+            auto it = std::partition(refs.begin() + b, refs.begin() + e, [=](const SahRef& r) {
+                int q = (int)((r.c[k] - base) * scale);
+                q = q < 0 ? 0 : (q >= NB ? NB - 1 : q);
+                return q <= best_bin;
+            });
+            mid = (int)(it - refs.begin());
+            if (mid == b || mid == e) mid = (b + e) / 2;
+        }
+        SahBox lb, rb;
+        const int c0 = build(b, mid, idx, lb);
+        const int c1 = build(mid, e, idx, rb);
+        float4* nd = nodes.data() + 4 * (size_t)idx;
+        nd[0] = make_float4(lb.lo[0], lb.lo[1], lb.lo[2], lb.hi[0]);
+        nd[1] = make_float4(lb.hi[1], lb.hi[2], rb.lo[0], rb.lo[1]);
+        nd[2] = make_float4(rb.lo[2], rb.hi[0], rb.hi[1], rb.hi[2]);
+        nd[3] = make_float4(int_bits_as_float(c0), int_bits_as_float(c1), 0.f, 0.f);
+        box.grow(lb.lo, lb.hi); box.grow(rb.lo, rb.hi);
+        return idx;
+    }
+};
+
+static hipError_t build_sah_host(int n, const float4* d_pbox, float4* d_nodes, int* d_parent, int* d_leaf_parent,
+                                 hipStream_t stream)
+{
+    std::vector<float4> pbox(2 * (size_t)n);
+    hipError_t e = hipMemcpyAsync(pbox.data(), d_pbox, pbox.size() * sizeof(float4), hipMemcpyDeviceToHost, stream);
+    if (e != hipSuccess) return e;
+    if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+    SahBuild B;
+    B.refs.resize(n);
+    for (int i = 0; i < n; ++i) {
+        SahRef& r = B.refs[i];
+        const float4 lo = pbox[2 * (size_t)i], hi = pbox[2 * (size_t)i + 1];
+        r.lo[0] = lo.x; r.lo[1] = lo.y; r.lo[2] = lo.z; r.hi[0] = hi.x; r.hi[1] = hi.y; r.hi[2] = hi.z;
+        for (int k = 0; k < 3; ++k) r.c[k] = 0.5f * (r.lo[k] + r.hi[k]);
+        r.id = i;
+    }
+    B.nodes.resize(4 * (size_t)(n - 1));
+    B.parent.assign(n - 1, -1);
+    B.leaf_parent.assign(n, -1);
+    SahBox root;
+    B.build(0, n, -1, root);
+    if (B.next != n - 1) return hipErrorUnknown;
+    if ((e = hipMemcpyAsync(d_nodes, B.nodes.data(), B.nodes.size() * sizeof(float4), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
+    if ((e = hipMemcpyAsync(d_parent, B.parent.data(), (size_t)(n - 1) * 4, hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
+    if ((e = hipMemcpyAsync(d_leaf_parent, B.leaf_parent.data(), (size_t)n * 4, hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
+    return hipStreamSynchronize(stream);   // the host vectors go out of scope
+}
+
 #define BCHK(expr) do { e = (expr); if (e != hipSuccess) goto done; } while (0)
 
 hipError_t vrt_build_lbvh(const DevScene& S, float4* nodes, float4* wide, int* depth_out, float* ms_out,
-                          bool radix_tree, bool parity_collapse, hipStream_t stream)
+                          int builder, bool parity_collapse, hipStream_t stream)
 {
     const int n = S.n_prims;
     hipError_t e = hipSuccess;
@@ -465,10 +598,13 @@ hipError_t vrt_build_lbvh(const DevScene& S, float4* nodes, float4* wide, int* d
     BCHK(hipMemsetAsync(depth, 0, 4, stream));
     BCHK(hipEventRecord(e0, stream));
     hipLaunchKernelGGL(k_prim_bounds, dim3(blocks), dim3(256), 0, stream, S, pbox, cb);
+    if (builder == 2) {
+        BCHK(build_sah_host(n, pbox, nodes, parent, leaf_parent, stream));
+    } else {
     hipLaunchKernelGGL(k_morton, dim3(blocks), dim3(256), 0, stream, n, pbox, cb, keys, vals);
     BCHK(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys2, vals, vals2, (size_t)n, 0, 63, stream));
     {
-        const bool ploc = !radix_tree;
+        const bool ploc = builder != 1;
         if (ploc) {
             // cluster arrays, ping-pong; `parked` (4 float4 per node) holds the four box arrays
             int *code_a = nullptr, *code_b = nullptr, *nn = nullptr;
@@ -514,6 +650,7 @@ ploc_done:
             hipLaunchKernelGGL(k_fit, dim3(blocks), dim3(256), 0, stream, n, vals2, pbox, child, parent, leaf_parent, arrived,
                                parked, nodes);
         }
+    }
     }
     hipLaunchKernelGGL(k_depth, dim3(blocks), dim3(256), 0, stream, n, parent, leaf_parent, depth);
     {

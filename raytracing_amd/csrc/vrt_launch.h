@@ -67,10 +67,10 @@ namespace vrt_fused { VRT_LAUNCHERS }
 // binary nodes (with parent indices) to `nodes` and 8*(n_prims-1) float4 of 4-wide nodes to `wide`
 // (slots of absorbed nodes stay unwritten).  Returns the binary tree depth in *depth_out.
 // Synchronises the stream.
-// radix_tree: Karras' radix tree instead of PLOC clustering; parity_collapse: every second level
+// builder: 0 PLOC clustering, 1 Karras' radix tree, 2 binned SAH built on the host; parity_collapse: every second level
 // becomes a wide node instead of the surface-area-guided collapse.
 hipError_t vrt_build_lbvh(const DevScene& S, float4* nodes, float4* wide, int* depth_out, float* ms_out,
-                          bool radix_tree, bool parity_collapse, hipStream_t stream);
+                          int builder, bool parity_collapse, hipStream_t stream);
 
 // process_color over n pixels: 3 floats in, 4 floats out.
 hipError_t vrt_launch_tonemap(const float* rgb, float4* rgba, size_t n, hipStream_t stream);

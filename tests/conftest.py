@@ -35,7 +35,7 @@ def vrt_ctx():
 
 
 OPTION_DEFAULTS = dict(xcd_remap=0, sample_shift=-1, wf_defer=1, wf_refill=1, wf_max_slots=0, wf_any_cap=-1, wf_queue_cap=0,
-                       builder=0, collapse_parity=0, no_big=0, packet=-1, beam=-1, block_compact=0, quad_max=-1, stack_cap=0, slab_fma=1, fail_after_build=0)
+                       builder=-1, collapse_parity=0, no_big=0, packet=-1, beam=-1, block_compact=0, quad_max=-1, stack_cap=0, slab_fma=1, fail_after_build=0)
 
 
 @pytest.fixture
