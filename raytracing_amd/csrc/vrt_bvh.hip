@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstring>
+#include <thread>
 #include <vector>
 #include <rocprim/rocprim.hpp>
 
@@ -434,7 +435,7 @@ __global__ __launch_bounds__(256) void k_store_parents(int n_inner, const int* _
 //
 // Top-down build by the surface-area heuristic with 16 bins per axis over the primitives'
 // centroids (Wald 2007), one primitive per leaf, for scenes whose tree is built once and traced
-// many times: the padded primitive boxes come from k_prim_bounds, the binary nodes, parent and
+// many times (large scenes on up to 16 host threads): the padded primitive boxes come from k_prim_bounds, the binary nodes, parent and
 // leaf-parent arrays go back to the device in the layout k_ploc_emit writes, and the 4-wide
 // collapse runs on them as on any other binary tree.  Node 0 is the root (preorder numbering).
 static inline float int_bits_as_float(int v) { float f; memcpy(&f, &v, 4); return f; }
@@ -455,10 +456,12 @@ struct SahBuild {
     std::vector<SahRef> refs;
     std::vector<float4> nodes;
     std::vector<int> parent, leaf_parent;
-    int next = 0;
 
-    // builds refs[b, e); returns the child code and the box
-    int build(int b, int e, int parent_idx, SahBox& box)
+    // Builds refs[b, e) into the inner nodes idx .. idx + (e - b) - 2 (a subtree over m primitives
+    // has m - 1 inner nodes, so preorder numbers follow from the range and need no shared
+    // counter: subtrees can be built by different threads and the tree is the same whoever
+    // builds which).  Returns the child code and the box.  spawn: levels that may still fork.
+    int build(int b, int e, int parent_idx, int idx, SahBox& box, int spawn)
     {
         if (e - b == 1) {
             const SahRef& r = refs[b];
@@ -466,7 +469,6 @@ struct SahBuild {
             box.grow(r.lo, r.hi);
             return ~r.id;
         }
-        const int idx = next++;
         parent[idx] = parent_idx;
         float cl[3] = {INFINITY, INFINITY, INFINITY}, ch[3] = {-INFINITY, -INFINITY, -INFINITY};
         for (int i = b; i < e; ++i)
@@ -521,8 +523,16 @@ struct SahBuild {
             if (mid == b || mid == e) mid = (b + e) / 2;
         }
         SahBox lb, rb;
-        const int c0 = build(b, mid, idx, lb);
-        const int c1 = build(mid, e, idx, rb);
+        int c0, c1;
+        const int left_idx = idx + 1, right_idx = idx + (mid - b);
+        if (spawn > 0 && e - b > 32768) {
+            std::thread t([&] { c0 = build(b, mid, idx, left_idx, lb, spawn - 1); });
+            c1 = build(mid, e, idx, right_idx, rb, spawn - 1);
+            t.join();
+        } else {
+            c0 = build(b, mid, idx, left_idx, lb, 0);
+            c1 = build(mid, e, idx, right_idx, rb, 0);
+        }
         float4* nd = nodes.data() + 4 * (size_t)idx;
         nd[0] = make_float4(lb.lo[0], lb.lo[1], lb.lo[2], lb.hi[0]);
         nd[1] = make_float4(lb.hi[1], lb.hi[2], rb.lo[0], rb.lo[1]);
@@ -553,8 +563,7 @@ static hipError_t build_sah_host(int n, const float4* d_pbox, float4* d_nodes, i
     B.parent.assign(n - 1, -1);
     B.leaf_parent.assign(n, -1);
     SahBox root;
-    B.build(0, n, -1, root);
-    if (B.next != n - 1) return hipErrorUnknown;
+    B.build(0, n, -1, 0, root, 4);   // up to 16 threads near the root
     if ((e = hipMemcpyAsync(d_nodes, B.nodes.data(), B.nodes.size() * sizeof(float4), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
     if ((e = hipMemcpyAsync(d_parent, B.parent.data(), (size_t)(n - 1) * 4, hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
     if ((e = hipMemcpyAsync(d_leaf_parent, B.leaf_parent.data(), (size_t)n * 4, hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
