@@ -461,7 +461,7 @@ struct SahBuild {
     // has m - 1 inner nodes, so preorder numbers follow from the range and need no shared
     // counter: subtrees can be built by different threads and the tree is the same whoever
     // builds which).  Returns the child code and the box.  spawn: levels that may still fork.
-    int build(int b, int e, int parent_idx, int idx, SahBox& box, int spawn)
+    int build(int b, int e, int parent_idx, int idx, SahBox& box, int spawn, int depth = 0)
     {
         if (e - b == 1) {
             const SahRef& r = refs[b];
@@ -476,7 +476,9 @@ struct SahBuild {
         constexpr int NB = VRT_SAH_BINS;
         float best = INFINITY;
         int best_axis = -1, best_bin = 0;
-        for (int k = 0; k < 3; ++k) {
+        // (beyond 48 levels only median splits: a contrived scene cannot make the tree, and the
+        // recursion, deeper than 48 + log2 n)
+        for (int k = 0; k < 3 && depth < 48; ++k) {
             const float ext = ch[k] - cl[k];
             if (!(ext > 0.f)) continue;
             const float scale = NB / ext;
@@ -509,7 +511,14 @@ struct SahBuild {
         }
         int mid;
         if (best_axis < 0) {
-            mid = (b + e) / 2;   // all centroids coincide
+            // all centroids coincide, or the depth bound: halve the range along its longest axis
+            int k = 0;
+            if (ch[1] - cl[1] > ch[k] - cl[k]) k = 1;
+            if (ch[2] - cl[2] > ch[k] - cl[k]) k = 2;
+            mid = (b + e) / 2;
+            std::nth_element(refs.begin() + b, refs.begin() + mid, refs.begin() + e, [k](const SahRef& x, const SahRef& y) {
+                return x.c[k] < y.c[k] || (x.c[k] == y.c[k] && x.id < y.id);
+            });
         } else {
             const int k = best_axis;
             const float scale = NB / (ch[k] - cl[k]);
@@ -526,12 +535,12 @@ struct SahBuild {
         int c0, c1;
         const int left_idx = idx + 1, right_idx = idx + (mid - b);
         if (spawn > 0 && e - b > 32768) {
-            std::thread t([&] { c0 = build(b, mid, idx, left_idx, lb, spawn - 1); });
-            c1 = build(mid, e, idx, right_idx, rb, spawn - 1);
+            std::thread t([&] { c0 = build(b, mid, idx, left_idx, lb, spawn - 1, depth + 1); });
+            c1 = build(mid, e, idx, right_idx, rb, spawn - 1, depth + 1);
             t.join();
         } else {
-            c0 = build(b, mid, idx, left_idx, lb, 0);
-            c1 = build(mid, e, idx, right_idx, rb, 0);
+            c0 = build(b, mid, idx, left_idx, lb, 0, depth + 1);
+            c1 = build(mid, e, idx, right_idx, rb, 0, depth + 1);
         }
         float4* nd = nodes.data() + 4 * (size_t)idx;
         nd[0] = make_float4(lb.lo[0], lb.lo[1], lb.lo[2], lb.hi[0]);

@@ -97,3 +97,27 @@ def test_camera_inside_a_collider_and_zero_viewport(vrt_ctx, oracle_mod):
     cam0 = ra.make_camera((1, 2, 3), (1, 2, 3), (0, 0, 0), (0, 0, 0), 8, 8)
     rgba, hit, st = _cmp(vrt_ctx, oracle_mod, s, cam0, ra.Params(spp=1, max_depth=3))
     assert sum(st.rays) == 0 and np.all(hit == -1)
+
+
+def test_geometric_progression_of_primitives(vrt_ctx, oracle_mod):
+    """Spheres whose centres and radii shrink geometrically towards a point: every binned split of
+    the surface-area build peels a few of them off, so the tree wants to be hundreds of levels
+    deep; the builder bounds its depth (median splits beyond 48 levels) and the frame must still be
+    the oracle's, whatever the builder."""
+    s = ra.Scene()
+    m = s.add_material("Metal", abi.VRT_MAT_METAL, (0.9, 0.8, 0.7))
+    b = s.add_material("Blue", abi.VRT_MAT_SOLID, (0.1, 0.3, 1.0))
+    for k in range(400):
+        f = 0.9 ** k
+        s.add_sphere((-1.8 + 3.6 * f, 0.2 + 1.5 * f, 0.5), 0.35 * f, m if k % 3 else b)
+    s.add_box((0, -0.5, 0), (6, 0.5, 6), b)
+    s.add_light(abi.VRT_LIGHT_POINT, (0, 8, -2), cast_shadows=True)
+    prm = ra.Params(spp=1, max_depth=4)
+    ref, ref_hit, st = _cmp(vrt_ctx, oracle_mod, s, _cam(96, 72), prm)
+    vrt_ctx.set_option("builder", 0)
+    try:
+        vrt_ctx.set_scene(s)
+        got, got_hit, _ = vrt_ctx.render(prm)
+    finally:
+        vrt_ctx.set_option("builder", -1)
+    assert np.array_equal(got, ref, equal_nan=True) and np.array_equal(got_hit, ref_hit)
