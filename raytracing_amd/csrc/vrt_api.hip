@@ -100,7 +100,7 @@ extern "C" int vrt_set_option(vrt_ctx* c, const char* name, long long value)
     else if (n == "wf_max_slots") o.wf_max_slots = value > 0 ? value : 0;
     else if (n == "wf_any_cap") o.wf_any_cap = value;
     else if (n == "wf_queue_cap") o.wf_queue_cap = value > 0 ? value : 0;
-    else if (n == "builder") { if (value < -1 || value > 2) return fail(c, VRT_ERR_INVALID, "builder: -1 by scene size, 0 PLOC, 1 radix tree, 2 SAH on the host"); o.builder = (int)value; }
+    else if (n == "builder") { if (value < -1 || value > 3) return fail(c, VRT_ERR_INVALID, "builder: -1 by scene size, 0 PLOC, 1 radix tree, 2 SAH on the host, 3 SAH on the device"); o.builder = (int)value; }
     else if (n == "collapse_parity") o.collapse_parity = value != 0;
     else if (n == "no_big") o.no_big = value != 0;
     else if (n == "block_compact") o.block_compact = value != 0;
@@ -506,10 +506,10 @@ static int build_scene(vrt_ctx* c, const vrt_scene_desc* d, SceneBufs& sb)
         HIPCHK(c, hipMalloc(&sb.d_bvh, 4 * (size_t)(n_prims - 1) * sizeof(float4)));
         HIPCHK(c, hipMalloc(&sb.d_bvh4, 8 * (size_t)(n_prims - 1) * sizeof(float4)));
         S.bvh = sb.d_bvh; S.bvh4 = sb.d_bvh4;
-        // Binned SAH on the host (one thread, 0.43 s per million primitives) buys 10 % of the frame
-        // time over PLOC on the device (10 ms per million); beyond a few million primitives the
-        // set-up time would be felt, so PLOC takes over.
-        const int builder = c->opt.builder >= 0 ? c->opt.builder : (n_prims <= 4000000 ? 2 : 0);
+        // Binned SAH (on the device, one wave per node and level: 7 ms for 10 k spheres, 0.12 s per
+        // million triangles) buys 10 % of the frame time over PLOC (10 ms per million); beyond a few
+        // million primitives the set-up time would be felt, so PLOC takes over.
+        const int builder = c->opt.builder >= 0 ? c->opt.builder : (n_prims <= 4000000 ? 3 : 0);
         hipError_t e = vrt_build_lbvh(S, sb.d_bvh, sb.d_bvh4, &sb.bvh_depth, &sb.bvh_ms,
                                       builder, c->opt.collapse_parity != 0, c->stream);
         if (e != hipSuccess) return fail(c, VRT_ERR_HIP, std::string("LBVH build: ") + hipGetErrorString(e));

@@ -420,6 +420,210 @@ __global__ __launch_bounds__(256) void k_collapse4_level(const float4* __restric
     w[7] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
+// ------------------------------------------------------------------ binned SAH build on the device
+//
+// The same top-down build as build_sah_host (16 bins per axis over the centroids, one primitive
+// per leaf), level by level: one wave per node of the level.  The wave reads its primitives
+// (contiguous in `in`), reduces the centroid bounds, bins into its part of LDS (ordered-uint
+// min/max, integer counts), three lanes sweep one axis each, and a stable two-sided partition
+// writes the primitives to the same range of `out`, accumulating both children's boxes on the
+// way, so the node is complete when the wave is.  A subtree over m primitives has m - 1 inner
+// nodes, hence the children's preorder numbers are idx + 1 and idx + n_left: no counter, and the
+// tree does not depend on scheduling.  Children of two or more primitives join the next level's
+// queue.  Beyond level 48 ranges are halved by index (depth bound for contrived scenes).
+struct SahTask { int b, e, idx, parent; };
+#define VRT_SAH_NB 16
+
+__device__ __forceinline__ float sah_wave_min(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float sah_wave_max(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float sah_area(const float lo[3], const float hi[3])
+{
+    const float x = hi[0] - lo[0], y = hi[1] - lo[1], z = hi[2] - lo[2];
+    return x < 0.f ? 0.f : x * y + y * z + z * x;
+}
+
+__global__ __launch_bounds__(256) void k_sah_level(int level, const float4* __restrict__ in, float4* __restrict__ out,
+                                                   const SahTask* __restrict__ in_q, int n_in,
+                                                   SahTask* __restrict__ out_q, int* __restrict__ out_count,
+                                                   float4* __restrict__ nodes, int* __restrict__ parent,
+                                                   int* __restrict__ leaf_parent)
+{
+    // per wave: 3 axes x 16 bins x (count, lo[3], hi[3]) and two words for the ids of one-primitive children
+    __shared__ unsigned s_bins[4][3 * VRT_SAH_NB * 7 + 2];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + wave;
+    if (t >= n_in) return;   // whole waves leave
+    const SahTask task = in_q[t];
+    const int b = task.b, e = task.e, idx = task.idx, m = e - b;
+    unsigned* bins = s_bins[wave];
+    if (lane == 0) parent[idx] = task.parent;
+
+    // 1. centroid bounds
+    float cl[3] = {INFINITY, INFINITY, INFINITY}, ch[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = b + lane; i < e; i += 64) {
+        const float4 lo = in[2 * (size_t)i], hi = in[2 * (size_t)i + 1];
+        const float c[3] = {0.5f * (lo.x + hi.x), 0.5f * (lo.y + hi.y), 0.5f * (lo.z + hi.z)};
+        for (int k = 0; k < 3; ++k) { cl[k] = fminf(cl[k], c[k]); ch[k] = fmaxf(ch[k], c[k]); }
+    }
+    for (int k = 0; k < 3; ++k) { cl[k] = sah_wave_min(cl[k]); ch[k] = sah_wave_max(ch[k]); }
+
+    // 2. bins
+    int best_axis = -1, best_bin = 0;
+    if (level < 48 && (ch[0] > cl[0] || ch[1] > cl[1] || ch[2] > cl[2])) {
+        for (int w = lane; w < 3 * VRT_SAH_NB * 7; w += 64) {
+            const int f = w % 7;
+            bins[w] = f == 0 ? 0u : (f <= 3 ? 0xffffffffu : 0u);   // count, lo (min), hi (max) as ordered uints
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        float scale[3];
+        for (int k = 0; k < 3; ++k) scale[k] = ch[k] > cl[k] ? VRT_SAH_NB / (ch[k] - cl[k]) : 0.f;
+        for (int i = b + lane; i < e; i += 64) {
+            const float4 lo = in[2 * (size_t)i], hi = in[2 * (size_t)i + 1];
+            const float c[3] = {0.5f * (lo.x + hi.x), 0.5f * (lo.y + hi.y), 0.5f * (lo.z + hi.z)};
+            const float l3[3] = {lo.x, lo.y, lo.z}, h3[3] = {hi.x, hi.y, hi.z};
+            for (int k = 0; k < 3; ++k) {
+                if (!(ch[k] > cl[k])) continue;
+                int q = (int)((c[k] - cl[k]) * scale[k]);
+                q = q < 0 ? 0 : (q >= VRT_SAH_NB ? VRT_SAH_NB - 1 : q);
+                unsigned* bin = bins + (k * VRT_SAH_NB + q) * 7;
+                atomicAdd(&bin[0], 1u);
+                for (int a = 0; a < 3; ++a) { atomicMin(&bin[1 + a], enc_f(l3[a])); atomicMax(&bin[4 + a], enc_f(h3[a])); }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // 3. lanes 0..2 sweep one axis each
+        float my_cost = INFINITY;
+        int my_bin = 0;
+        if (lane < 3 && ch[lane] > cl[lane]) {
+            const unsigned* ax = bins + lane * VRT_SAH_NB * 7;
+            float right_area[VRT_SAH_NB];
+            int right_cnt[VRT_SAH_NB];
+            float alo[3] = {INFINITY, INFINITY, INFINITY}, ahi[3] = {-INFINITY, -INFINITY, -INFINITY};
+            int n_acc = 0;
+            for (int q = VRT_SAH_NB - 1; q > 0; --q) {
+                const unsigned* bin = ax + q * 7;
+                if (bin[0]) for (int a = 0; a < 3; ++a) { alo[a] = fminf(alo[a], dec_f(bin[1 + a])); ahi[a] = fmaxf(ahi[a], dec_f(bin[4 + a])); }
+                n_acc += (int)bin[0];
+                right_area[q] = sah_area(alo, ahi); right_cnt[q] = n_acc;
+            }
+            float llo[3] = {INFINITY, INFINITY, INFINITY}, lhi[3] = {-INFINITY, -INFINITY, -INFINITY};
+            int n_left = 0;
+            for (int q = 0; q < VRT_SAH_NB - 1; ++q) {
+                const unsigned* bin = ax + q * 7;
+                if (bin[0]) for (int a = 0; a < 3; ++a) { llo[a] = fminf(llo[a], dec_f(bin[1 + a])); lhi[a] = fmaxf(lhi[a], dec_f(bin[4 + a])); }
+                n_left += (int)bin[0];
+                if (n_left == 0 || right_cnt[q + 1] == 0) continue;
+                const float cost = sah_area(llo, lhi) * n_left + right_area[q + 1] * right_cnt[q + 1];
+                if (cost < my_cost) { my_cost = cost; my_bin = q; }
+            }
+        }
+        // the first axis with the smallest cost, as the host build picks it
+        float best = INFINITY;
+        for (int k = 0; k < 3; ++k) {
+            const float ck = __shfl(my_cost, k, 64);
+            const int bk = __shfl(my_bin, k, 64);
+            if (ck < best) { best = ck; best_axis = k; best_bin = bk; }
+        }
+    }
+
+    // 4. stable partition into `out`, the children's boxes on the way
+    float scale_k = 0.f, base_k = 0.f;
+    if (best_axis >= 0) { base_k = cl[best_axis]; scale_k = VRT_SAH_NB / (ch[best_axis] - cl[best_axis]); }
+    auto goes_left = [&](const float4& lo, const float4& hi, int i) {
+        if (best_axis < 0) return false;
+        const float c = best_axis == 0 ? 0.5f * (lo.x + hi.x) : (best_axis == 1 ? 0.5f * (lo.y + hi.y) : 0.5f * (lo.z + hi.z));
+        int q = (int)((c - base_k) * scale_k);
+        q = q < 0 ? 0 : (q >= VRT_SAH_NB ? VRT_SAH_NB - 1 : q);
+        return q <= best_bin;
+    };
+    int n_left = 0;
+    if (best_axis >= 0) {
+        for (int base = 0; base < m; base += 64) {
+            const int i = b + base + lane;
+            bool p = false;
+            if (i < e) p = goes_left(in[2 * (size_t)i], in[2 * (size_t)i + 1], i);
+            n_left += __popcll(__ballot(p));
+        }
+    }
+    const bool by_index = best_axis < 0 || n_left == 0 || n_left == m;   // no usable split: halve by index
+    if (by_index) n_left = m / 2;
+    float llo[3] = {INFINITY, INFINITY, INFINITY}, lhi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    float rlo[3] = {INFINITY, INFINITY, INFINITY}, rhi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    int off_l = 0, off_r = 0;
+    for (int base = 0; base < m; base += 64) {
+        const int i = b + base + lane;
+        const bool valid = i < e;
+        float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
+        bool p = false;
+        if (valid) {
+            lo = in[2 * (size_t)i]; hi = in[2 * (size_t)i + 1];
+            p = by_index ? (i - b) < n_left : goes_left(lo, hi, i);
+        }
+        const unsigned long long ml = __ballot(valid && p), mr = __ballot(valid && !p);
+        if (valid) {
+            const unsigned long long mine = p ? ml : mr;
+            const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mine >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mine, 0u));
+            const int dest = p ? b + off_l + rank : b + n_left + off_r + rank;
+            out[2 * (size_t)dest] = lo; out[2 * (size_t)dest + 1] = hi;
+            const float l3[3] = {lo.x, lo.y, lo.z}, h3[3] = {hi.x, hi.y, hi.z};
+            if (p) for (int a = 0; a < 3; ++a) { llo[a] = fminf(llo[a], l3[a]); lhi[a] = fmaxf(lhi[a], h3[a]); }
+            else   for (int a = 0; a < 3; ++a) { rlo[a] = fminf(rlo[a], l3[a]); rhi[a] = fmaxf(rhi[a], h3[a]); }
+            // a child of one primitive is a leaf: its id is the fourth word of the primitive's lo
+            if (p && n_left == 1) bins[3 * VRT_SAH_NB * 7] = __float_as_uint(lo.w);
+            if (!p && m - n_left == 1) bins[3 * VRT_SAH_NB * 7 + 1] = __float_as_uint(lo.w);
+        }
+        off_l += __popcll(ml); off_r += __popcll(mr);
+    }
+    for (int a = 0; a < 3; ++a) {
+        llo[a] = sah_wave_min(llo[a]); lhi[a] = sah_wave_max(lhi[a]);
+        rlo[a] = sah_wave_min(rlo[a]); rhi[a] = sah_wave_max(rhi[a]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // 5. the node and its children
+    if (lane == 0) {
+        const int n_right = m - n_left;
+        const int idx_l = idx + 1, idx_r = idx + n_left;
+        int c0, c1;
+        if (n_left == 1) { const int id = (int)bins[3 * VRT_SAH_NB * 7]; c0 = ~id; leaf_parent[id] = idx; } else c0 = idx_l;
+        if (n_right == 1) { const int id = (int)bins[3 * VRT_SAH_NB * 7 + 1]; c1 = ~id; leaf_parent[id] = idx; } else c1 = idx_r;
+        float4* nd = nodes + 4 * (size_t)idx;
+        nd[0] = make_float4(llo[0], llo[1], llo[2], lhi[0]);
+        nd[1] = make_float4(lhi[1], lhi[2], rlo[0], rlo[1]);
+        nd[2] = make_float4(rlo[2], rhi[0], rhi[1], rhi[2]);
+        nd[3] = make_float4(__int_as_float(c0), __int_as_float(c1), 0.f, 0.f);
+        const int n_new = (n_left > 1) + (n_right > 1);
+        if (n_new) {
+            int at = atomicAdd(out_count, n_new);
+            if (n_left > 1) { SahTask q = {b, b + n_left, idx_l, idx}; out_q[at++] = q; }
+            if (n_right > 1) { SahTask q = {b + n_left, e, idx_r, idx}; out_q[at] = q; }
+        }
+    }
+}
+
+// Primitive boxes with the primitive id in the fourth word of lo: the records the build moves around.
+__global__ __launch_bounds__(256) void k_sah_refs(int n, const float4* __restrict__ pbox, float4* __restrict__ refs)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float4 lo = pbox[2 * (size_t)i], hi = pbox[2 * (size_t)i + 1];
+    lo.w = __int_as_float(i);   // (the id's bit pattern; never used as a number)
+    refs[2 * (size_t)i] = lo; refs[2 * (size_t)i + 1] = hi;
+}
+
 // Writes every binary node's parent index into word 2 of its fourth float4 (-1 at the root): the
 // stackless walk that finishes a query whose traversal stack overflowed climbs with it.
 __global__ __launch_bounds__(256) void k_store_parents(int n_inner, const int* __restrict__ parent, float4* __restrict__ nodes)
@@ -579,6 +783,41 @@ static hipError_t build_sah_host(int n, const float4* d_pbox, float4* d_nodes, i
     return hipStreamSynchronize(stream);   // the host vectors go out of scope
 }
 
+static hipError_t build_sah_device(int n, const float4* d_pbox, float4* d_nodes, int* d_parent, int* d_leaf_parent,
+                                   hipStream_t stream)
+{
+    float4 *ref_a = nullptr, *ref_b = nullptr;
+    SahTask *q_a = nullptr, *q_b = nullptr;
+    int* count = nullptr;
+    hipError_t e = hipSuccess;
+#define SCHK(expr) do { e = (expr); if (e != hipSuccess) goto sah_done; } while (0)
+    SCHK(hipMalloc(&ref_a, 2 * (size_t)n * sizeof(float4)));
+    SCHK(hipMalloc(&ref_b, 2 * (size_t)n * sizeof(float4)));
+    SCHK(hipMalloc(&q_a, (size_t)n * sizeof(SahTask)));
+    SCHK(hipMalloc(&q_b, (size_t)n * sizeof(SahTask)));
+    SCHK(hipMalloc(&count, sizeof(int)));
+    hipLaunchKernelGGL(k_sah_refs, dim3((n + 255) / 256), dim3(256), 0, stream, n, d_pbox, ref_a);
+    {
+        const SahTask root = {0, n, 0, -1};
+        SCHK(hipMemcpyAsync(q_a, &root, sizeof root, hipMemcpyHostToDevice, stream));
+        int n_in = 1;
+        for (int level = 0; n_in > 0 && level < 4096; ++level) {
+            SCHK(hipMemsetAsync(count, 0, sizeof(int), stream));
+            hipLaunchKernelGGL(k_sah_level, dim3((n_in + 3) / 4), dim3(256), 0, stream, level, ref_a, ref_b, q_a, n_in, q_b, count,
+                               d_nodes, d_parent, d_leaf_parent);
+            SCHK(hipMemcpyAsync(&n_in, count, sizeof(int), hipMemcpyDeviceToHost, stream));
+            SCHK(hipStreamSynchronize(stream));
+            float4* tr = ref_a; ref_a = ref_b; ref_b = tr;
+            SahTask* tq = q_a; q_a = q_b; q_b = tq;
+        }
+        if (n_in > 0) e = hipErrorUnknown;
+    }
+sah_done:
+#undef SCHK
+    hipFree(ref_a); hipFree(ref_b); hipFree(q_a); hipFree(q_b); hipFree(count);
+    return e;
+}
+
 #define BCHK(expr) do { e = (expr); if (e != hipSuccess) goto done; } while (0)
 
 hipError_t vrt_build_lbvh(const DevScene& S, float4* nodes, float4* wide, int* depth_out, float* ms_out,
@@ -618,6 +857,8 @@ hipError_t vrt_build_lbvh(const DevScene& S, float4* nodes, float4* wide, int* d
     hipLaunchKernelGGL(k_prim_bounds, dim3(blocks), dim3(256), 0, stream, S, pbox, cb);
     if (builder == 2) {
         BCHK(build_sah_host(n, pbox, nodes, parent, leaf_parent, stream));
+    } else if (builder == 3) {
+        BCHK(build_sah_device(n, pbox, nodes, parent, leaf_parent, stream));
     } else {
     hipLaunchKernelGGL(k_morton, dim3(blocks), dim3(256), 0, stream, n, pbox, cb, keys, vals);
     BCHK(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys2, vals, vals2, (size_t)n, 0, 63, stream));

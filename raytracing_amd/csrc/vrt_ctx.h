@@ -20,7 +20,7 @@ struct VrtOptions {
     long long wf_max_slots = 0; // wavefront: sample slots per band (0 = library default)
     long long wf_queue_cap = 0; // wavefront, tests: ray queues cut to this many entries (0 = as allocated)
     long long wf_any_cap = -1;  // wavefront: capacity of the occlusion-query queue (-1 = full)
-    int builder = -1;           // binary tree under the 4-wide collapse: 0 PLOC, 1 Karras' radix tree, 2 binned SAH built on the host, -1 = SAH up to 4 M primitives, else PLOC
+    int builder = -1;           // binary tree under the 4-wide collapse: 0 PLOC, 1 Karras' radix tree, 2 binned SAH built on the host, 3 the same on the device, -1 = 3 up to 4 M primitives, else PLOC
     int collapse_parity = 0;    // 1: collapse every second level instead of by surface area
     int no_big = 0;             // 1: scene-sized primitives stay in the tree
     int packet = -1;            // tree scenes: wave-uniform traversal for the rays of one pixel group; -1 = chosen from spp

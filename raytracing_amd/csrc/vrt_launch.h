@@ -67,7 +67,7 @@ namespace vrt_fused { VRT_LAUNCHERS }
 // binary nodes (with parent indices) to `nodes` and 8*(n_prims-1) float4 of 4-wide nodes to `wide`
 // (slots of absorbed nodes stay unwritten).  Returns the binary tree depth in *depth_out.
 // Synchronises the stream.
-// builder: 0 PLOC clustering, 1 Karras' radix tree, 2 binned SAH built on the host; parity_collapse: every second level
+// builder: 0 PLOC clustering, 1 Karras' radix tree, 2 binned SAH built on the host, 3 binned SAH built on the device; parity_collapse: every second level
 // becomes a wide node instead of the surface-area-guided collapse.
 hipError_t vrt_build_lbvh(const DevScene& S, float4* nodes, float4* wide, int* depth_out, float* ms_out,
                           int builder, bool parity_collapse, hipStream_t stream);

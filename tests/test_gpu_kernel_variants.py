@@ -126,7 +126,7 @@ def test_wavefront_bands_equal_megakernel(vrt_ctx, vrt_opts, spp):
 
 @pytest.mark.parametrize("which", ["spheres", "mesh"])
 def test_frames_do_not_depend_on_the_tree(vrt_ctx, vrt_opts, which):
-    """Closest hits are ranked by (t, id), so the builder (PLOC, the radix tree, SAH on the host), the collapse
+    """Closest hits are ranked by (t, id), so the builder (PLOC, the radix tree, SAH on the host or on the device), the collapse
     (surface-area-guided or every second level) and keeping scene-sized primitives in or out of
     the tree must all give the same frame, hit ids and ray counts, bit for bit."""
     if which == "spheres":
@@ -136,8 +136,8 @@ def test_frames_do_not_depend_on_the_tree(vrt_ctx, vrt_opts, which):
     prm = ra.Params(spp=2, max_depth=5, rng=rng)
     names = ("builder", "collapse_parity", "no_big")
     results = []
-    for opts in ({}, {"builder": 1}, {"builder": 2}, {"collapse_parity": 1}, {"builder": 1, "collapse_parity": 1, "no_big": 1},
-                 {"builder": 2, "collapse_parity": 1}):
+    for opts in ({}, {"builder": 1}, {"builder": 2}, {"builder": 3}, {"collapse_parity": 1},
+                 {"builder": 1, "collapse_parity": 1, "no_big": 1}, {"builder": 2, "collapse_parity": 1}, {"builder": 3, "no_big": 1}):
         for k in names:
             vrt_opts(k, opts.get(k, 0))   # builder 0 = PLOC
         vrt_ctx.set_scene(scene)   # the tree is built here
