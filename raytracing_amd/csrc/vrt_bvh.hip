@@ -614,6 +614,317 @@ __global__ __launch_bounds__(256) void k_sah_level(int level, const float4* __re
     }
 }
 
+// ------------------------------------------------------------------ large nodes of the SAH build
+//
+// One wave per node leaves the chip idle while the tree is still narrow: the root of a 1 M
+// triangle scene is one wave walking a million primitives three times.  Nodes of more than
+// VRT_SAH_BIG primitives are therefore split by many blocks, VRT_SAH_CHUNK primitives each, in
+// four launches per level: k_big_bin (LDS bins per block, merged into the node's bins with integer
+// atomics), k_big_count (every block repeats the node's sweep, counts the primitives of its chunk
+// that go left), k_big_scatter (stable partition: a chunk's offsets are the counts of the chunks
+// before it; the children's boxes and centroid bounds are gathered with ordered-uint atomics, so
+// no pass over the children is needed to start on them) and k_big_finish (node record, children
+// queued as large or small tasks).  Bins, counts, minima and maxima are exact whatever the order of
+// the atomics, and the partition is stable, so the tree is the one the one-wave build produces.
+// Minima are kept as maxima of the complemented code, which lets one memset of zeros reset a level.
+#define VRT_SAH_BIG 4096
+#define VRT_SAH_CHUNK 1024
+#define VRT_SAH_BIN_WORDS (3 * VRT_SAH_NB * 7)
+
+// Decodes a minimum kept as the maximum of complemented codes: dec_fc(v).  (Written on the
+// complemented word directly; hipcc 7.2 crashes in instruction selection on dec_fc(v) for gfx950.)
+__device__ __forceinline__ float dec_fc(unsigned v)
+{
+    return __uint_as_float((v & 0x80000000u) ? v : (v ^ 0x7fffffffu));
+}
+
+struct BigTask {
+    int b, e, idx, parent;
+    int chunk0, n_chunks;
+    unsigned cb[6];        // centroid bounds as ordered uints: minima x y z, maxima x y z
+};
+struct BigSplit { int axis, bin, n_left, by_index; float base, scale; };
+struct BigOut {
+    unsigned box[12];      // left lo[3] (complemented), left hi[3], right lo[3] (complemented), right hi[3]
+    unsigned cen[12];      // the same for the children's centroids
+    unsigned leaf[2];      // primitive id of a child of one primitive
+    unsigned pad[2];
+};
+
+// The node's split from its bins (the sweep of k_sah_level, step 3) and from them the number of
+// primitives that go left.  Called by one whole wave; the result is valid in every lane.
+__device__ __forceinline__ BigSplit big_split(int level, const BigTask& T, const unsigned* __restrict__ bins, int lane)
+{
+    float cl[3], ch[3];
+    for (int k = 0; k < 3; ++k) { cl[k] = dec_f(T.cb[k]); ch[k] = dec_f(T.cb[3 + k]); }
+    const int m = T.e - T.b;
+    int best_axis = -1, best_bin = 0;
+    if (level < 48 && (ch[0] > cl[0] || ch[1] > cl[1] || ch[2] > cl[2])) {
+        float my_cost = INFINITY;
+        int my_bin = 0;
+        if (lane < 3 && ch[lane] > cl[lane]) {
+            const unsigned* ax = bins + lane * VRT_SAH_NB * 7;
+            float right_area[VRT_SAH_NB];
+            int right_cnt[VRT_SAH_NB];
+            float alo[3] = {INFINITY, INFINITY, INFINITY}, ahi[3] = {-INFINITY, -INFINITY, -INFINITY};
+            int n_acc = 0;
+            for (int q = VRT_SAH_NB - 1; q > 0; --q) {
+                const unsigned* bin = ax + q * 7;
+                if (bin[0]) for (int a = 0; a < 3; ++a) { alo[a] = fminf(alo[a], dec_fc(bin[1 + a])); ahi[a] = fmaxf(ahi[a], dec_f(bin[4 + a])); }
+                n_acc += (int)bin[0];
+                right_area[q] = sah_area(alo, ahi); right_cnt[q] = n_acc;
+            }
+            float llo[3] = {INFINITY, INFINITY, INFINITY}, lhi[3] = {-INFINITY, -INFINITY, -INFINITY};
+            int n_left = 0;
+            for (int q = 0; q < VRT_SAH_NB - 1; ++q) {
+                const unsigned* bin = ax + q * 7;
+                if (bin[0]) for (int a = 0; a < 3; ++a) { llo[a] = fminf(llo[a], dec_fc(bin[1 + a])); lhi[a] = fmaxf(lhi[a], dec_f(bin[4 + a])); }
+                n_left += (int)bin[0];
+                if (n_left == 0 || right_cnt[q + 1] == 0) continue;
+                const float cost = sah_area(llo, lhi) * n_left + right_area[q + 1] * right_cnt[q + 1];
+                if (cost < my_cost) { my_cost = cost; my_bin = q; }
+            }
+        }
+        float best = INFINITY;
+        for (int k = 0; k < 3; ++k) {
+            const float ck = __shfl(my_cost, k, 64);
+            const int bk = __shfl(my_bin, k, 64);
+            if (ck < best) { best = ck; best_axis = k; best_bin = bk; }
+        }
+    }
+    BigSplit s;
+    s.axis = best_axis; s.bin = best_bin; s.n_left = 0; s.base = 0.f; s.scale = 0.f;
+    if (best_axis >= 0) {
+        s.base = cl[best_axis]; s.scale = VRT_SAH_NB / (ch[best_axis] - cl[best_axis]);
+        for (int q = 0; q <= best_bin; ++q) s.n_left += (int)bins[(best_axis * VRT_SAH_NB + q) * 7];
+    }
+    s.by_index = best_axis < 0 || s.n_left == 0 || s.n_left == m;
+    if (s.by_index) s.n_left = m / 2;
+    return s;
+}
+
+__device__ __forceinline__ bool big_goes_left(const BigSplit& s, const float4& lo, const float4& hi, int i_rel)
+{
+    if (s.by_index) return i_rel < s.n_left;
+    const float c = s.axis == 0 ? 0.5f * (lo.x + hi.x) : (s.axis == 1 ? 0.5f * (lo.y + hi.y) : 0.5f * (lo.z + hi.z));
+    int q = (int)((c - s.base) * s.scale);
+    q = q < 0 ? 0 : (q >= VRT_SAH_NB ? VRT_SAH_NB - 1 : q);
+    return q <= s.bin;
+}
+
+// The root as a large task: its centroid bounds are those k_prim_bounds gathered.
+__global__ __launch_bounds__(256) void k_big_root(int n, const unsigned* __restrict__ cb, BigTask* __restrict__ tasks,
+                                                  int* __restrict__ chunk_task)
+{
+    const int n_chunks = (n + VRT_SAH_CHUNK - 1) / VRT_SAH_CHUNK;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        BigTask T;
+        T.b = 0; T.e = n; T.idx = 0; T.parent = -1; T.chunk0 = 0; T.n_chunks = n_chunks;
+        for (int k = 0; k < 6; ++k) T.cb[k] = cb[k];
+        tasks[0] = T;
+    }
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < n_chunks; j += gridDim.x * 256) chunk_task[j] = 0;
+}
+
+__global__ __launch_bounds__(256) void k_big_bin(int level, const float4* __restrict__ in, const BigTask* __restrict__ tasks,
+                                                 const int* __restrict__ chunk_task, unsigned* __restrict__ bins)
+{
+    __shared__ unsigned s_bins[VRT_SAH_BIN_WORDS];
+    const int t = chunk_task[blockIdx.x];
+    const BigTask T = tasks[t];
+    float cl[3], ch[3], scale[3];
+    for (int k = 0; k < 3; ++k) {
+        cl[k] = dec_f(T.cb[k]); ch[k] = dec_f(T.cb[3 + k]);
+        scale[k] = ch[k] > cl[k] ? VRT_SAH_NB / (ch[k] - cl[k]) : 0.f;
+    }
+    if (!(level < 48 && (ch[0] > cl[0] || ch[1] > cl[1] || ch[2] > cl[2]))) return;   // the whole task: halved by index
+    for (int w = threadIdx.x; w < VRT_SAH_BIN_WORDS; w += 256) s_bins[w] = 0u;
+    __syncthreads();
+    const int first = T.b + (blockIdx.x - T.chunk0) * VRT_SAH_CHUNK;
+    const int last = first + VRT_SAH_CHUNK < T.e ? first + VRT_SAH_CHUNK : T.e;
+    for (int i = first + threadIdx.x; i < last; i += 256) {
+        const float4 lo = in[2 * (size_t)i], hi = in[2 * (size_t)i + 1];
+        const float c[3] = {0.5f * (lo.x + hi.x), 0.5f * (lo.y + hi.y), 0.5f * (lo.z + hi.z)};
+        const float l3[3] = {lo.x, lo.y, lo.z}, h3[3] = {hi.x, hi.y, hi.z};
+        for (int k = 0; k < 3; ++k) {
+            if (!(ch[k] > cl[k])) continue;
+            int q = (int)((c[k] - cl[k]) * scale[k]);
+            q = q < 0 ? 0 : (q >= VRT_SAH_NB ? VRT_SAH_NB - 1 : q);
+            unsigned* bin = s_bins + (k * VRT_SAH_NB + q) * 7;
+            atomicAdd(&bin[0], 1u);
+            for (int a = 0; a < 3; ++a) { atomicMax(&bin[1 + a], ~enc_f(l3[a])); atomicMax(&bin[4 + a], enc_f(h3[a])); }
+        }
+    }
+    __syncthreads();
+    unsigned* g = bins + (size_t)t * VRT_SAH_BIN_WORDS;
+    for (int w = threadIdx.x; w < VRT_SAH_BIN_WORDS; w += 256) {
+        const unsigned v = s_bins[w];
+        if (!v) continue;
+        if (w % 7 == 0) atomicAdd(&g[w], v); else atomicMax(&g[w], v);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_big_count(int level, const float4* __restrict__ in, const BigTask* __restrict__ tasks,
+                                                   const int* __restrict__ chunk_task, const unsigned* __restrict__ bins,
+                                                   BigSplit* __restrict__ split, int* __restrict__ left_count)
+{
+    __shared__ BigSplit s_split;
+    __shared__ int s_cnt;
+    const int t = chunk_task[blockIdx.x];
+    const BigTask T = tasks[t];
+    const int c = blockIdx.x - T.chunk0;
+    if (threadIdx.x < 64) {
+        const BigSplit s = big_split(level, T, bins + (size_t)t * VRT_SAH_BIN_WORDS, threadIdx.x);
+        if (threadIdx.x == 0) { s_split = s; s_cnt = 0; if (c == 0) split[t] = s; }
+    }
+    __syncthreads();
+    const BigSplit s = s_split;
+    const int first = T.b + c * VRT_SAH_CHUNK;
+    const int last = first + VRT_SAH_CHUNK < T.e ? first + VRT_SAH_CHUNK : T.e;
+    int mine = 0;
+    for (int i = first + threadIdx.x; i < last; i += 256)
+        mine += big_goes_left(s, in[2 * (size_t)i], in[2 * (size_t)i + 1], i - T.b) ? 1 : 0;
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&s_cnt, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) left_count[blockIdx.x] = s_cnt;
+}
+
+__global__ __launch_bounds__(256) void k_big_scatter(const float4* __restrict__ in, float4* __restrict__ out,
+                                                     const BigTask* __restrict__ tasks, const int* __restrict__ chunk_task,
+                                                     const BigSplit* __restrict__ split, const int* __restrict__ left_count,
+                                                     BigOut* __restrict__ outs)
+{
+    __shared__ int s_before;
+    __shared__ int s_wl[4], s_wr[4];
+    const int t = chunk_task[blockIdx.x];
+    const BigTask T = tasks[t];
+    const BigSplit s = split[t];
+    const int c = blockIdx.x - T.chunk0;
+    const int wave = threadIdx.x >> 6;
+    const int m = T.e - T.b;
+    if (threadIdx.x == 0) s_before = 0;
+    __syncthreads();
+    {   // primitives of the chunks before this one that go left
+        int acc = 0;
+        for (int j = threadIdx.x; j < c; j += 256) acc += left_count[T.chunk0 + j];
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        if ((threadIdx.x & 63) == 0 && acc) atomicAdd(&s_before, acc);
+    }
+    __syncthreads();
+    int run_l = s_before, run_r = c * VRT_SAH_CHUNK - s_before;
+    float llo[3] = {INFINITY, INFINITY, INFINITY}, lhi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    float rlo[3] = {INFINITY, INFINITY, INFINITY}, rhi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    float lcl[3] = {INFINITY, INFINITY, INFINITY}, lch[3] = {-INFINITY, -INFINITY, -INFINITY};
+    float rcl[3] = {INFINITY, INFINITY, INFINITY}, rch[3] = {-INFINITY, -INFINITY, -INFINITY};
+    bool any_l = false, any_r = false;
+    const int first = T.b + c * VRT_SAH_CHUNK;
+    for (int base = 0; base < VRT_SAH_CHUNK; base += 256) {   // block-uniform trip count
+        const int i = first + base + threadIdx.x;
+        const bool valid = i < T.e;
+        float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
+        bool p = false;
+        if (valid) {
+            lo = in[2 * (size_t)i]; hi = in[2 * (size_t)i + 1];
+            p = big_goes_left(s, lo, hi, i - T.b);
+        }
+        const unsigned long long ml = __ballot(valid && p), mr = __ballot(valid && !p);
+        if ((threadIdx.x & 63) == 0) { s_wl[wave] = __popcll(ml); s_wr[wave] = __popcll(mr); }
+        __syncthreads();
+        int pre_l = 0, pre_r = 0, tot_l = 0, tot_r = 0;
+        for (int w = 0; w < 4; ++w) {
+            if (w < wave) { pre_l += s_wl[w]; pre_r += s_wr[w]; }
+            tot_l += s_wl[w]; tot_r += s_wr[w];
+        }
+        if (valid) {
+            const unsigned long long mine = p ? ml : mr;
+            const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mine >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mine, 0u));
+            const int dest = p ? T.b + run_l + pre_l + rank : T.b + s.n_left + run_r + pre_r + rank;
+            out[2 * (size_t)dest] = lo; out[2 * (size_t)dest + 1] = hi;
+            const float l3[3] = {lo.x, lo.y, lo.z}, h3[3] = {hi.x, hi.y, hi.z};
+            const float c3[3] = {0.5f * (lo.x + hi.x), 0.5f * (lo.y + hi.y), 0.5f * (lo.z + hi.z)};
+            if (p) {
+                any_l = true;
+                for (int a = 0; a < 3; ++a) {
+                    llo[a] = fminf(llo[a], l3[a]); lhi[a] = fmaxf(lhi[a], h3[a]);
+                    lcl[a] = fminf(lcl[a], c3[a]); lch[a] = fmaxf(lch[a], c3[a]);
+                }
+                if (s.n_left == 1) outs[t].leaf[0] = __float_as_uint(lo.w);
+            } else {
+                any_r = true;
+                for (int a = 0; a < 3; ++a) {
+                    rlo[a] = fminf(rlo[a], l3[a]); rhi[a] = fmaxf(rhi[a], h3[a]);
+                    rcl[a] = fminf(rcl[a], c3[a]); rch[a] = fmaxf(rch[a], c3[a]);
+                }
+                if (m - s.n_left == 1) outs[t].leaf[1] = __float_as_uint(lo.w);
+            }
+        }
+        run_l += tot_l; run_r += tot_r;
+        __syncthreads();
+    }
+    const bool wave_l = __any(any_l), wave_r = __any(any_r);
+    for (int a = 0; a < 3; ++a) {
+        llo[a] = sah_wave_min(llo[a]); lhi[a] = sah_wave_max(lhi[a]); rlo[a] = sah_wave_min(rlo[a]); rhi[a] = sah_wave_max(rhi[a]);
+        lcl[a] = sah_wave_min(lcl[a]); lch[a] = sah_wave_max(lch[a]); rcl[a] = sah_wave_min(rcl[a]); rch[a] = sah_wave_max(rch[a]);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        BigOut& O = outs[t];
+        if (wave_l) for (int a = 0; a < 3; ++a) {
+            atomicMax(&O.box[a], ~enc_f(llo[a])); atomicMax(&O.box[3 + a], enc_f(lhi[a]));
+            atomicMax(&O.cen[a], ~enc_f(lcl[a])); atomicMax(&O.cen[3 + a], enc_f(lch[a]));
+        }
+        if (wave_r) for (int a = 0; a < 3; ++a) {
+            atomicMax(&O.box[6 + a], ~enc_f(rlo[a])); atomicMax(&O.box[9 + a], enc_f(rhi[a]));
+            atomicMax(&O.cen[6 + a], ~enc_f(rcl[a])); atomicMax(&O.cen[9 + a], enc_f(rch[a]));
+        }
+    }
+}
+
+// One lane per large task: the node record (step 5 of k_sah_level) and the children as tasks of
+// the next level, large ones with their chunk numbers and centroid bounds.
+__global__ __launch_bounds__(64) void k_big_finish(int n_big, const BigTask* __restrict__ tasks, const BigSplit* __restrict__ split,
+                                                   const BigOut* __restrict__ outs, float4* __restrict__ nodes,
+                                                   int* __restrict__ parent, int* __restrict__ leaf_parent,
+                                                   SahTask* __restrict__ out_q, int* __restrict__ counts,
+                                                   BigTask* __restrict__ next_tasks, int* __restrict__ next_chunk_task)
+{
+    const int t = blockIdx.x * 64 + threadIdx.x;
+    if (t >= n_big) return;
+    const BigTask T = tasks[t];
+    const unsigned* __restrict__ box = outs[t].box;   // read in place: a copy indexed by `side` would live in scratch
+    const unsigned* __restrict__ cen = outs[t].cen;
+    const int n_left = split[t].n_left, m = T.e - T.b, n_right = m - n_left;
+    const int idx = T.idx, idx_l = idx + 1, idx_r = idx + n_left;
+    parent[idx] = T.parent;
+    int c0, c1;
+    if (n_left == 1) { const int id = (int)outs[t].leaf[0]; c0 = ~id; leaf_parent[id] = idx; } else c0 = idx_l;
+    if (n_right == 1) { const int id = (int)outs[t].leaf[1]; c1 = ~id; leaf_parent[id] = idx; } else c1 = idx_r;
+    float4* nd = nodes + 4 * (size_t)idx;
+    nd[0] = make_float4(dec_fc(box[0]), dec_fc(box[1]), dec_fc(box[2]), dec_f(box[3]));
+    nd[1] = make_float4(dec_f(box[4]), dec_f(box[5]), dec_fc(box[6]), dec_fc(box[7]));
+    nd[2] = make_float4(dec_fc(box[8]), dec_f(box[9]), dec_f(box[10]), dec_f(box[11]));
+    nd[3] = make_float4(__int_as_float(c0), __int_as_float(c1), 0.f, 0.f);
+    for (int side = 0; side < 2; ++side) {
+        const int b = side ? T.b + n_left : T.b, e = side ? T.e : T.b + n_left, size = e - b;
+        const int child_idx = side ? idx_r : idx_l;
+        if (size <= 1) continue;
+        if (size > VRT_SAH_BIG) {
+            const int n_chunks = (size + VRT_SAH_CHUNK - 1) / VRT_SAH_CHUNK;
+            const int chunk0 = atomicAdd(&counts[2], n_chunks);
+            const int nt = atomicAdd(&counts[1], 1);
+            BigTask* N = next_tasks + nt;
+            N->b = b; N->e = e; N->idx = child_idx; N->parent = idx; N->chunk0 = chunk0; N->n_chunks = n_chunks;
+            const unsigned* cs = cen + 6 * side;
+            N->cb[0] = ~cs[0]; N->cb[1] = ~cs[1]; N->cb[2] = ~cs[2];
+            N->cb[3] = cs[3]; N->cb[4] = cs[4]; N->cb[5] = cs[5];
+            for (int j = 0; j < n_chunks; ++j) next_chunk_task[chunk0 + j] = nt;
+        } else {
+            SahTask* q = out_q + atomicAdd(&counts[0], 1);
+            q->b = b; q->e = e; q->idx = child_idx; q->parent = idx;
+        }
+    }
+}
+
 // Primitive boxes with the primitive id in the fourth word of lo: the records the build moves around.
 __global__ __launch_bounds__(256) void k_sah_refs(int n, const float4* __restrict__ pbox, float4* __restrict__ refs)
 {
@@ -783,38 +1094,78 @@ static hipError_t build_sah_host(int n, const float4* d_pbox, float4* d_nodes, i
     return hipStreamSynchronize(stream);   // the host vectors go out of scope
 }
 
-static hipError_t build_sah_device(int n, const float4* d_pbox, float4* d_nodes, int* d_parent, int* d_leaf_parent,
-                                   hipStream_t stream)
+static hipError_t build_sah_device(int n, const float4* d_pbox, const unsigned* d_cb, float4* d_nodes, int* d_parent,
+                                   int* d_leaf_parent, hipStream_t stream)
 {
     float4 *ref_a = nullptr, *ref_b = nullptr;
     SahTask *q_a = nullptr, *q_b = nullptr;
-    int* count = nullptr;
+    int* counts = nullptr;   // next level: small tasks, large tasks, chunks of the large tasks
+    // large tasks (more than VRT_SAH_BIG primitives, so at most n / VRT_SAH_BIG per level) and their chunks
+    const int max_big = n / VRT_SAH_BIG + 2, max_chunks = n / VRT_SAH_CHUNK + max_big + 2;
+    BigTask *big_a = nullptr, *big_b = nullptr;
+    int *chunk_a = nullptr, *chunk_b = nullptr, *left_count = nullptr;
+    BigSplit* split = nullptr;
+    unsigned* level_state = nullptr;   // per large task: bins, then the children's boxes; zeroed per level
+    const size_t bins_words = (size_t)max_big * VRT_SAH_BIN_WORDS;
+    const size_t state_bytes = bins_words * sizeof(unsigned) + (size_t)max_big * sizeof(BigOut);
     hipError_t e = hipSuccess;
 #define SCHK(expr) do { e = (expr); if (e != hipSuccess) goto sah_done; } while (0)
     SCHK(hipMalloc(&ref_a, 2 * (size_t)n * sizeof(float4)));
     SCHK(hipMalloc(&ref_b, 2 * (size_t)n * sizeof(float4)));
     SCHK(hipMalloc(&q_a, (size_t)n * sizeof(SahTask)));
     SCHK(hipMalloc(&q_b, (size_t)n * sizeof(SahTask)));
-    SCHK(hipMalloc(&count, sizeof(int)));
+    SCHK(hipMalloc(&counts, 3 * sizeof(int)));
+    SCHK(hipMalloc(&big_a, (size_t)max_big * sizeof(BigTask)));
+    SCHK(hipMalloc(&big_b, (size_t)max_big * sizeof(BigTask)));
+    SCHK(hipMalloc(&chunk_a, (size_t)max_chunks * sizeof(int)));
+    SCHK(hipMalloc(&chunk_b, (size_t)max_chunks * sizeof(int)));
+    SCHK(hipMalloc(&left_count, (size_t)max_chunks * sizeof(int)));
+    SCHK(hipMalloc(&split, (size_t)max_big * sizeof(BigSplit)));
+    SCHK(hipMalloc(&level_state, state_bytes));
     hipLaunchKernelGGL(k_sah_refs, dim3((n + 255) / 256), dim3(256), 0, stream, n, d_pbox, ref_a);
     {
-        const SahTask root = {0, n, 0, -1};
-        SCHK(hipMemcpyAsync(q_a, &root, sizeof root, hipMemcpyHostToDevice, stream));
-        int n_in = 1;
-        for (int level = 0; n_in > 0 && level < 4096; ++level) {
-            SCHK(hipMemsetAsync(count, 0, sizeof(int), stream));
-            hipLaunchKernelGGL(k_sah_level, dim3((n_in + 3) / 4), dim3(256), 0, stream, level, ref_a, ref_b, q_a, n_in, q_b, count,
-                               d_nodes, d_parent, d_leaf_parent);
-            SCHK(hipMemcpyAsync(&n_in, count, sizeof(int), hipMemcpyDeviceToHost, stream));
+        int n_in = 0, n_big = 0, n_chunks = 0;
+        if (n > VRT_SAH_BIG) {
+            n_big = 1; n_chunks = (n + VRT_SAH_CHUNK - 1) / VRT_SAH_CHUNK;
+            hipLaunchKernelGGL(k_big_root, dim3((n_chunks + 255) / 256), dim3(256), 0, stream, n, d_cb, big_a, chunk_a);
+        } else {
+            const SahTask root = {0, n, 0, -1};
+            SCHK(hipMemcpyAsync(q_a, &root, sizeof root, hipMemcpyHostToDevice, stream));
+            n_in = 1;
+        }
+        for (int level = 0; (n_in > 0 || n_big > 0) && level < 4096; ++level) {
+            int h[3] = {0, 0, 0};
+            SCHK(hipMemsetAsync(counts, 0, 3 * sizeof(int), stream));
+            if (n_big > 0) {
+                if (n_big > max_big || n_chunks > max_chunks) { e = hipErrorUnknown; goto sah_done; }   // cannot happen: tasks are disjoint ranges
+                unsigned* bins = level_state;
+                BigOut* outs = (BigOut*)(level_state + bins_words);
+                SCHK(hipMemsetAsync(level_state, 0, state_bytes, stream));
+                hipLaunchKernelGGL(k_big_bin, dim3(n_chunks), dim3(256), 0, stream, level, ref_a, big_a, chunk_a, bins);
+                hipLaunchKernelGGL(k_big_count, dim3(n_chunks), dim3(256), 0, stream, level, ref_a, big_a, chunk_a, bins, split,
+                                   left_count);
+                hipLaunchKernelGGL(k_big_scatter, dim3(n_chunks), dim3(256), 0, stream, ref_a, ref_b, big_a, chunk_a, split,
+                                   left_count, outs);
+                hipLaunchKernelGGL(k_big_finish, dim3((n_big + 63) / 64), dim3(64), 0, stream, n_big, big_a, split, outs, d_nodes,
+                                   d_parent, d_leaf_parent, q_b, counts, big_b, chunk_b);
+            }
+            if (n_in > 0)
+                hipLaunchKernelGGL(k_sah_level, dim3((n_in + 3) / 4), dim3(256), 0, stream, level, ref_a, ref_b, q_a, n_in, q_b,
+                                   counts, d_nodes, d_parent, d_leaf_parent);
+            SCHK(hipMemcpyAsync(h, counts, 3 * sizeof(int), hipMemcpyDeviceToHost, stream));
             SCHK(hipStreamSynchronize(stream));
+            n_in = h[0]; n_big = h[1]; n_chunks = h[2];
             float4* tr = ref_a; ref_a = ref_b; ref_b = tr;
             SahTask* tq = q_a; q_a = q_b; q_b = tq;
+            BigTask* tb = big_a; big_a = big_b; big_b = tb;
+            int* tc = chunk_a; chunk_a = chunk_b; chunk_b = tc;
         }
-        if (n_in > 0) e = hipErrorUnknown;
+        if (n_in > 0 || n_big > 0) e = hipErrorUnknown;
     }
 sah_done:
 #undef SCHK
-    hipFree(ref_a); hipFree(ref_b); hipFree(q_a); hipFree(q_b); hipFree(count);
+    hipFree(ref_a); hipFree(ref_b); hipFree(q_a); hipFree(q_b); hipFree(counts);
+    hipFree(big_a); hipFree(big_b); hipFree(chunk_a); hipFree(chunk_b); hipFree(left_count); hipFree(split); hipFree(level_state);
     return e;
 }
 
@@ -858,7 +1209,7 @@ hipError_t vrt_build_lbvh(const DevScene& S, float4* nodes, float4* wide, int* d
     if (builder == 2) {
         BCHK(build_sah_host(n, pbox, nodes, parent, leaf_parent, stream));
     } else if (builder == 3) {
-        BCHK(build_sah_device(n, pbox, nodes, parent, leaf_parent, stream));
+        BCHK(build_sah_device(n, pbox, cb, nodes, parent, leaf_parent, stream));
     } else {
     hipLaunchKernelGGL(k_morton, dim3(blocks), dim3(256), 0, stream, n, pbox, cb, keys, vals);
     BCHK(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys2, vals, vals2, (size_t)n, 0, 63, stream));

@@ -121,3 +121,37 @@ def test_geometric_progression_of_primitives(vrt_ctx, oracle_mod):
     finally:
         vrt_ctx.set_option("builder", -1)
     assert np.array_equal(got, ref, equal_nan=True) and np.array_equal(got_hit, ref_hit)
+
+
+def test_large_nodes_of_the_device_build(vrt_ctx, oracle_mod):
+    """Nodes of more than 4 096 primitives are split by many blocks (bins, counts, stable scatter
+    in separate launches).  Two scenes that push that path into its corners: 5 000 coincident
+    spheres (no usable split: large nodes are halved by index, level after level) next to a
+    spread-out set, and one far outlier beside 6 000 clustered spheres (a large node whose child
+    is a single primitive).  The frames must be the oracle's and those of the host-built tree."""
+    rng = np.random.default_rng(11)
+    for outlier in (False, True):
+        s = ra.Scene()
+        red = s.add_material("Red", abi.VRT_MAT_SOLID, (1.0, 0.2, 0.1))
+        met = s.add_material("Metal", abi.VRT_MAT_METAL, (0.9, 0.9, 0.9))
+        if outlier:
+            s.add_sphere((25.0, 0.5, 20.0), 0.5, met)
+            for p in rng.uniform((-1.5, 0.0, -0.5), (1.5, 2.0, 1.5), (6000, 3)):
+                s.add_sphere(tuple(p), 0.03, red)
+        else:
+            for _ in range(5000):
+                s.add_sphere((0.5, 0.8, 0.5), 0.4, met)
+            for p in rng.uniform((-2.0, 0.0, -0.5), (2.0, 2.0, 2.0), (1500, 3)):
+                s.add_sphere(tuple(p), 0.05, red)
+        s.add_box((0, -0.5, 0), (8, 0.5, 8), red)
+        s.add_light(abi.VRT_LIGHT_POINT, (0, 8, -2), cast_shadows=True)
+        prm = ra.Params(spp=1, max_depth=3)
+        ref, ref_hit, st = _cmp(vrt_ctx, oracle_mod, s, _cam(48, 36), prm)
+        assert st.bvh_nodes > 0
+        vrt_ctx.set_option("builder", 2)   # the same build on the host
+        try:
+            vrt_ctx.set_scene(s)
+            got, got_hit, _ = vrt_ctx.render(prm)
+        finally:
+            vrt_ctx.set_option("builder", -1)
+        assert np.array_equal(got, ref, equal_nan=True) and np.array_equal(got_hit, ref_hit)
