@@ -627,8 +627,12 @@ __global__ __launch_bounds__(256) void k_sah_level(int level, const float4* __re
 // queued as large or small tasks).  Bins, counts, minima and maxima are exact whatever the order of
 // the atomics, and the partition is stable, so the tree is the one the one-wave build produces.
 // Minima are kept as maxima of the complemented code, which lets one memset of zeros reset a level.
+#ifndef VRT_SAH_BIG
 #define VRT_SAH_BIG 4096
+#endif
+#ifndef VRT_SAH_CHUNK
 #define VRT_SAH_CHUNK 1024
+#endif
 #define VRT_SAH_BIN_WORDS (3 * VRT_SAH_NB * 7)
 
 // Decodes a minimum kept as the maximum of complemented codes: dec_fc(v).  (Written on the
