@@ -482,15 +482,19 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+        r0, r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
+        r0.record(stream)
         for _ in range(args.steps):
             step()
+        r1.record(stream)
         drain()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
+        region_kernel_ms.append(r0.elapsed_time(r1) / max(args.steps, 1))
         t = torch.tensor([el], dtype=torch.float64, device=cdev)
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)   # the slowest rank's clock, the same on every rank
@@ -499,11 +503,16 @@ def main():
     # The region is repeated until at least --min-time seconds have been timed (a 1080p frame takes
     # 0.15 ms: a few dozen steps are over before the clocks have settled); a step stays one frame,
     # and the figure reported is the median region.
+    region_kernel_ms = []   # HIP events on the launch stream around the same steps, per region
     regions = [timed_region()]
     n_rep = int(min(max(1, np.ceil(args.min_time / max(regions[0], 1e-9))), 200))
     for _ in range(n_rep - 1):
         regions.append(timed_region())
     elapsed = float(np.median(regions))
+    if world == 1:
+        # one GPU: a region's steps are the render launches and nothing else, so the kernel time that
+        # goes with `value` is the one the events measured over the very same launches
+        kernel_ms = float(np.median(region_kernel_ms))
 
     tot = torch.tensor([float(my_queries)], dtype=torch.float64, device=cdev)
     if world > 1:
@@ -567,7 +576,9 @@ def main():
             "roofline": roof,
         }
         if st.bvh_nodes:
-            out["config"]["bvh_build_ms"] = st.bvh_build_ms
+            out["config"]["bvh_build_ms"] = st.bvh_build_ms   # first build of the process (module load, first allocations)
+            ctx.set_scene(scene)                              # the same scene again: what a host that edits its scene pays
+            out["config"]["bvh_rebuild_ms"] = ctx.fetch_stats().bvh_build_ms
         if st.nodes_visited:  # only a library built with -DVRT_COUNT_NODES=1 counts these
             out["traversal"] = {"nodes_per_ray": st.nodes_visited / max(my_queries, 1),
                                 "prims_per_ray": st.prims_tested / max(my_queries, 1)}
