@@ -340,6 +340,9 @@ __device__ __forceinline__ bool slab_test(f3 lo, f3 hi, f3 o, f3 inv, float tmax
 #ifndef VRT_STACK_LANES
 #define VRT_STACK_LANES 64
 #endif
+#ifndef VRT_CC_EARLY
+#define VRT_CC_EARLY 1
+#endif
 __shared__ unsigned long long g_lds_stack[VRT_TRAV_STACK * VRT_STACK_LANES];
 
 // Orders two (tnear, code) candidates, nearer first.
@@ -509,6 +512,11 @@ __device__ __forceinline__ bool trav_inner(const DevScene& S, Trav& T, unsigned 
                  fz = *(const float4*)(base + (ez ^ 112u));
     const float4 cc = *(const float4*)(base + (at + 96u));
     int c0 = __float_as_int(cc.x), c1 = __float_as_int(cc.y), c2 = __float_as_int(cc.z), c3 = __float_as_int(cc.w);
+#if VRT_CC_EARLY
+    // keeps the load of the child codes with the loads of the planes: sunk into the "some child is
+    // hit" branch it is a second memory round trip on the way to the next node
+    asm volatile("" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3));
+#endif
     Slab4 r = slab4_signed(nx, ny, nz, fx, fy, fz, T.oi, T.inv, trav_limit(T));
 #else
     const float4* n = S.bvh4 + 8 * (size_t)T.node;
