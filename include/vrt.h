@@ -271,15 +271,17 @@ int vrt_create_multi(int n_gpus, const int* devices, vrt_ctx** out);
 
 /* Study and test knobs by name ("sample_shift", "packet", "beam", "slab_fma", "quad_max", "stack_cap",
  * "wf_defer", "wf_refill", "wf_max_slots", "wf_any_cap", "wf_queue_cap", "builder", "collapse_parity",
- * "no_big", "xcd_remap", "block_compact", "fail_after_build"); none changes a result.
+ * "no_big", "xcd_remap", "block_compact", "zero_copy", "fail_after_build"); none changes a result.
  * builder / collapse_parity / no_big take effect at the next vrt_set_scene.  No counterpart in
  * the reference. */
 int vrt_set_option(vrt_ctx* ctx, const char* name, long long value);
 
 /* Page-locked host memory for the frame the caller reads back over and over (the Color[]
  * PixelColorData of Info/TextureInformation.cs:36,58-63, which a Unity host wraps in a NativeArray):
- * vrt_render / vrt_render_begin copy into such a buffer at PCIe speed instead of through the
- * runtime's staging copies of pageable memory.  Freed by vrt_host_free or vrt_destroy.
+ * the frame kernels of vrt_render / vrt_render_begin / vrt_render_begin_parts store their pixels
+ * straight into such a buffer (it is mapped into the device's address space), so the frame crosses
+ * PCIe while it is being traced; hit ids are copied at PCIe speed instead of through the runtime's
+ * staging copies of pageable memory.  Freed by vrt_host_free or vrt_destroy.
  * vrt_host_register page-locks a buffer the caller allocated itself; the operating system may
  * refuse (VRT_ERR_HIP), in which case the buffer still works, only slower. */
 int vrt_host_alloc(vrt_ctx* ctx, uint64_t bytes, void** out);

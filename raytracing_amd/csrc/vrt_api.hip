@@ -82,6 +82,7 @@ static void options_from_env(VrtOptions& o)
     o.no_big = (int)geti("VRT_NO_BIG", 0);
     o.packet = (int)geti("VRT_PACKET", -1);
     o.block_compact = (int)geti("VRT_BLOCK_COMPACT", 0);
+    o.zero_copy = (int)geti("VRT_ZERO_COPY", 1);
     o.quad_max = (int)geti("VRT_QUAD_MAX", -1);
     o.beam = (int)geti("VRT_BEAM", -1);
     o.slab_fma = (int)geti("VRT_SLAB_FMA", 1);
@@ -104,6 +105,7 @@ extern "C" int vrt_set_option(vrt_ctx* c, const char* name, long long value)
     else if (n == "collapse_parity") o.collapse_parity = value != 0;
     else if (n == "no_big") o.no_big = value != 0;
     else if (n == "block_compact") o.block_compact = value != 0;
+    else if (n == "zero_copy") o.zero_copy = value != 0;
     else if (n == "slab_fma") o.slab_fma = value != 0;
     else if (n == "stack_cap") { if (value < 0 || value > VRT_TRAV_STACK) return fail(c, VRT_ERR_INVALID, "stack_cap: 0..VRT_TRAV_STACK"); o.stack_cap = (int)value; }
     else if (n == "quad_max") { if (value < -1 || value > 64) return fail(c, VRT_ERR_INVALID, "quad_max: -1..64"); o.quad_max = (int)value; }
@@ -156,6 +158,7 @@ static void teardown(vrt_ctx* c)
     c->registered.clear();
     for (void* p : c->host_allocs) hipHostFree(p);
     c->host_allocs.clear();
+    c->host_alloc_bytes.clear();
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
     if (c->ev_done) hipEventDestroy(c->ev_done);
@@ -229,6 +232,7 @@ extern "C" int vrt_host_alloc(vrt_ctx* c, uint64_t bytes, void** out)
     void* p = nullptr;
     HIPCHK(c, hipHostMalloc(&p, (size_t)bytes, hipHostMallocDefault));
     c->host_allocs.push_back(p);
+    c->host_alloc_bytes.push_back((size_t)bytes);
     *out = p;
     return VRT_OK;
 }
@@ -243,6 +247,7 @@ extern "C" int vrt_host_free(vrt_ctx* c, void* p)
             HIPCHK(c, hipStreamSynchronize(c->stream));
             HIPCHK(c, hipHostFree(p));
             c->host_allocs.erase(c->host_allocs.begin() + i);
+            c->host_alloc_bytes.erase(c->host_alloc_bytes.begin() + i);
             return VRT_OK;
         }
     return fail(c, VRT_ERR_INVALID, "buffer was not allocated with vrt_host_alloc on this context");
@@ -943,7 +948,8 @@ static int copy_rows_out(vrt_ctx* c, const DevParams& P, float* rgba_out, int32_
     if (P.tile_count <= 1 || P.compact) {
         const size_t nout = P.compact ? (size_t)P.local_rows * W : W * H;
         if (nout == 0) return VRT_OK;
-        HIPCHK(c, hipMemcpyAsync(rgba_out, c->d_rgba, nout * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+        if (rgba_out)   // null: the frame kernel has written the caller's buffer itself
+            HIPCHK(c, hipMemcpyAsync(rgba_out, c->d_rgba, nout * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
         if (hit_id_out)
             HIPCHK(c, hipMemcpyAsync(hit_id_out, c->d_hit, nout * sizeof(int), hipMemcpyDeviceToHost, c->stream));
         return VRT_OK;
@@ -965,9 +971,25 @@ static int copy_rows_out(vrt_ctx* c, const DevParams& P, float* rgba_out, int32_
                                   (size_t)tail_rows * W * px_bytes, hipMemcpyDeviceToHost, c->stream);
         return hipSuccess;
     };
-    HIPCHK(c, strided(rgba_out, c->d_rgba, sizeof(float4)));
+    if (rgba_out) HIPCHK(c, strided(rgba_out, c->d_rgba, sizeof(float4)));
     if (hit_id_out) HIPCHK(c, strided(hit_id_out, c->d_hit, sizeof(int)));
     return VRT_OK;
+}
+
+// The device's address of `p` when [p, p + bytes) lies inside a buffer of vrt_host_alloc, else null.
+// Such a buffer is page-locked and mapped into the device's address space, so a kernel can store
+// to it directly.
+static void* device_view_of_host_alloc(vrt_ctx* c, void* p, size_t bytes)
+{
+    for (size_t i = 0; i < c->host_allocs.size(); ++i) {
+        char* b = (char*)c->host_allocs[i];
+        if ((char*)p >= b && (char*)p + bytes <= b + c->host_alloc_bytes[i]) {
+            void* d = nullptr;
+            if (hipHostGetDevicePointer(&d, c->host_allocs[i], 0) != hipSuccess || !d) return nullptr;
+            return (char*)d + ((char*)p - b);
+        }
+    }
+    return nullptr;
 }
 
 // Enqueues one frame and its copies to the caller's buffers on the context's stream.
@@ -981,12 +1003,19 @@ static int begin_frame(vrt_ctx* c, const vrt_params* p, float* rgba_out, int32_t
     if (rc) return rc;
     rc = ensure_fb(c);
     if (rc) return rc;
+    // A frame buffer from vrt_host_alloc is written by the frame kernel itself: its 128-byte row
+    // segments cross PCIe while the rest of the frame is still being traced, instead of in a copy
+    // that starts when the kernel has ended (1080p: 0.78 -> 0.72 ms; the device time of the frame
+    // in vrt_stats then includes the transfer).  Hit ids, 32 bytes per row segment, are slower that
+    // way than in one copy and keep going through the device buffer.
+    const size_t rows_out = P.compact ? (size_t)P.local_rows : (size_t)c->cam.height;
+    float4* direct = c->opt.zero_copy ? (float4*)device_view_of_host_alloc(c, rgba_out, rows_out * c->cam.width * sizeof(float4)) : nullptr;
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-    rc = enqueue_frame(c, p, P, c->d_rgba, hit_id_out ? c->d_hit : nullptr, c->stream);
+    rc = enqueue_frame(c, p, P, direct ? direct : c->d_rgba, hit_id_out ? c->d_hit : nullptr, c->stream);
     if (rc) return rc;
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));
     c->timed = true;
-    return copy_rows_out(c, P, rgba_out, hit_id_out);
+    return copy_rows_out(c, P, direct ? nullptr : rgba_out, hit_id_out);
 }
 
 extern "C" int vrt_render(vrt_ctx* c, const vrt_params* p, float* rgba_out, int32_t* hit_id_out, vrt_stats* stats_out)
@@ -1047,17 +1076,19 @@ extern "C" int vrt_render_begin_parts(vrt_ctx* c, const vrt_params* p, float* rg
     if (rc) return rc;
     HIPCHK(c, hipMemsetAsync(c->d_ctr, 0, kCtrBlock * sizeof(unsigned long long), c->stream));
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    // as in begin_frame: a buffer of vrt_host_alloc is written by the kernels themselves
+    float4* direct = c->opt.zero_copy ? (float4*)device_view_of_host_alloc(c, rgba_out, (size_t)c->cam.height * c->cam.width * sizeof(float4)) : nullptr;
     uint64_t pixels = 0;
     for (int k = 0; k < n_parts; ++k) {
         q.tile_index = k;
         DevParams P;
         rc = prepare(c, &q, &P);
         if (rc) return rc;
-        rc = enqueue_frame(c, &q, P, c->d_rgba, hit_id_out ? c->d_hit : nullptr, c->stream, c->d_ctr);
+        rc = enqueue_frame(c, &q, P, direct ? direct : c->d_rgba, hit_id_out ? c->d_hit : nullptr, c->stream, c->d_ctr);
         if (rc) return rc;
         pixels += c->last_pixels;
         if (k == n_parts - 1) HIPCHK(c, hipEventRecord(c->ev1, c->stream));
-        rc = copy_rows_out(c, P, rgba_out, hit_id_out);
+        rc = copy_rows_out(c, P, direct ? nullptr : rgba_out, hit_id_out);
         if (rc) return rc;
         HIPCHK(c, hipEventRecord(c->part_ev[k], c->stream));
     }

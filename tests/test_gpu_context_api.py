@@ -235,3 +235,39 @@ def test_wavefront_overflow_is_reported_without_stats(vrt_ctx, vrt_opts):
     vrt_opts("wf_queue_cap", 0)
     again, _, st = vrt_ctx.render(prm)
     assert np.array_equal(again, ref, equal_nan=True) and list(st.rays) == list(ref_st.rays)
+
+
+def test_frames_stored_straight_into_page_locked_buffers(vrt_ctx):
+    """A frame buffer from vrt_host_alloc is written by the frame kernels themselves instead of
+    being copied after them.  Same bits as with the copy (option zero_copy off) for whole frames in
+    both kernel organisations, for one strip set of three (the other rows keep what the caller had
+    there), for packed rows, and for a frame that starts part-way into the allocation."""
+    scene, cam, kw = _spheres(96, 64)
+    vrt_ctx.set_scene(scene)
+    vrt_ctx.set_camera(cam)
+    ref, ref_hit, ref_st = vrt_ctx.render(ra.Params(**kw))
+    big = vrt_ctx.host_alloc((2 * cam.height, cam.width, 4), np.float32)
+    try:
+        for mode in (abi.VRT_MODE_MEGAKERNEL, abi.VRT_MODE_WAVEFRONT):
+            for zc in (1, 0):
+                vrt_ctx.set_option("zero_copy", zc)
+                big[:] = -3.0
+                out = big[5:5 + cam.height]          # not at the start of the allocation
+                _, hit, st = vrt_ctx.render(ra.Params(mode=mode, **kw), rgba=out)
+                assert np.array_equal(out, ref, equal_nan=True) and np.array_equal(hit, ref_hit)
+                assert list(st.rays) == list(ref_st.rays)
+                assert (big[:5] == -3.0).all() and (big[5 + cam.height:] == -3.0).all()
+        for zc in (1, 0):
+            vrt_ctx.set_option("zero_copy", zc)
+            big[:] = -3.0
+            out = big[:cam.height]
+            vrt_ctx.render(ra.Params(tile_index=1, tile_count=3, tile_rows=8, **kw), rgba=out)
+            mine = np.array([(h // 8) % 3 == 1 for h in range(cam.height)])
+            assert np.array_equal(out[mine], ref[mine], equal_nan=True) and (out[~mine] == -3.0).all()
+            big[:] = -3.0
+            vrt_ctx.render(ra.Params(tile_index=1, tile_count=3, tile_rows=8, compact_rows=True, **kw), rgba=out)
+            n = int(mine.sum())
+            assert np.array_equal(out[:n], ref[mine], equal_nan=True) and (out[n:] == -3.0).all()
+    finally:
+        vrt_ctx.set_option("zero_copy", 1)
+        vrt_ctx.host_free(big)
