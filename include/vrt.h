@@ -271,7 +271,7 @@ int vrt_create_multi(int n_gpus, const int* devices, vrt_ctx** out);
 
 /* Study and test knobs by name ("sample_shift", "packet", "beam", "slab_fma", "quad_max", "stack_cap",
  * "wf_defer", "wf_refill", "wf_max_slots", "wf_any_cap", "wf_queue_cap", "builder", "collapse_parity",
- * "no_big", "xcd_remap", "block_compact", "zero_copy", "fail_after_build"); none changes a result.
+ * "no_big", "xcd_remap", "block_compact", "zero_copy", "staged", "fail_after_build"); none changes a result.
  * builder / collapse_parity / no_big take effect at the next vrt_set_scene.  No counterpart in
  * the reference. */
 int vrt_set_option(vrt_ctx* ctx, const char* name, long long value);
@@ -305,7 +305,9 @@ int vrt_set_camera(vrt_ctx* ctx, const vrt_camera* cam);
 /* Whole frame: the loop Update → DoRayTraceArchitecture → UpdateScene over every pixel
  * (RayTracerUnity.cs:312-352,565-597,607-617).  rgba_out = width*height*4 floats
  * (PixelColorData layout, index h*width+v), hit_id_out = width*height int32 primary
- * primitive ids of sample 0 (may be NULL). */
+ * primitive ids of sample 0 (may be NULL).  The buffers may be any host memory: a buffer of
+ * vrt_host_alloc is written by the frame kernel itself, pageable memory (a pinned managed array)
+ * is filled band by band from page-locked staging while the next band is traced. */
 int vrt_render(vrt_ctx* ctx, const vrt_params* params, float* rgba_out,
                int32_t* hit_id_out, vrt_stats* stats_out);
 

@@ -7,6 +7,7 @@
 #include <string>
 #include <algorithm>
 #include <utility>
+#include <thread>
 #include <vector>
 
 #include "vrt_ctx.h"
@@ -83,6 +84,7 @@ static void options_from_env(VrtOptions& o)
     o.packet = (int)geti("VRT_PACKET", -1);
     o.block_compact = (int)geti("VRT_BLOCK_COMPACT", 0);
     o.zero_copy = (int)geti("VRT_ZERO_COPY", 1);
+    o.staged = (int)geti("VRT_STAGED", 1);
     o.quad_max = (int)geti("VRT_QUAD_MAX", -1);
     o.beam = (int)geti("VRT_BEAM", -1);
     o.slab_fma = (int)geti("VRT_SLAB_FMA", 1);
@@ -106,6 +108,7 @@ extern "C" int vrt_set_option(vrt_ctx* c, const char* name, long long value)
     else if (n == "no_big") o.no_big = value != 0;
     else if (n == "block_compact") o.block_compact = value != 0;
     else if (n == "zero_copy") o.zero_copy = value != 0;
+    else if (n == "staged") o.staged = value != 0;
     else if (n == "slab_fma") o.slab_fma = value != 0;
     else if (n == "stack_cap") { if (value < 0 || value > VRT_TRAV_STACK) return fail(c, VRT_ERR_INVALID, "stack_cap: 0..VRT_TRAV_STACK"); o.stack_cap = (int)value; }
     else if (n == "quad_max") { if (value < -1 || value > 64) return fail(c, VRT_ERR_INVALID, "quad_max: -1..64"); o.quad_max = (int)value; }
@@ -1018,12 +1021,91 @@ static int begin_frame(vrt_ctx* c, const vrt_params* p, float* rgba_out, int32_t
     return copy_rows_out(c, P, direct ? nullptr : rgba_out, hit_id_out);
 }
 
+// vrt_render for a whole frame into memory the device cannot reach, i.e. pageable memory such as a
+// managed Color[] pinned with GCHandle (the runtime copies into such memory through its own
+// staging at about a third of the PCIe rate).  The frame is rendered in VRT_STAGED_BANDS bands of
+// rows straight into page-locked staging of the context (the frame kernel stores there, see
+// begin_frame), hit ids copied per band, and this thread copies a band to the caller's buffer as
+// soon as its event has fired, while the next band is being traced.  Returns 1 when the call is
+// not of that kind and the ordinary path has to take it.
+#define VRT_STAGED_BANDS 8
+#define VRT_STAGED_THREADS 2   // 4 bands: +3 %, 16: +12 %; more threads change nothing (1080p, MI355X host)
+static int render_staged(vrt_ctx* c, const vrt_params* p, float* rgba_out, int32_t* hit_id_out, vrt_stats* stats_out)
+{
+    if (!c->opt.staged || !c->have_cam || p->tile_count > 1 || p->compact_rows || (p->flags & VRT_OUT_LINEAR_RGB)) return 1;
+    const size_t W = (size_t)c->cam.width, H = (size_t)c->cam.height, px = W * H;
+    if (px < (size_t)1 << 18) return 1;   // small frames: the bands' launches would cost more than they hide
+    HIPCHK(c, hipSetDevice(c->device));
+    hipPointerAttribute_t at;
+    // memory the runtime knows (page-locked or device) is copied at PCIe speed as it is; an
+    // unknown pointer is reported as an error by older runtimes and as "unregistered" by newer ones
+    if (hipPointerGetAttributes(&at, rgba_out) == hipSuccess && at.type != hipMemoryTypeUnregistered) return 1;
+    (void)hipGetLastError();
+    if (px > c->stage_px) {
+        if (c->stage_rgba) { vrt_host_free(c, c->stage_rgba); c->stage_rgba = nullptr; }
+        if (c->stage_hit) { vrt_host_free(c, c->stage_hit); c->stage_hit = nullptr; }
+        c->stage_px = 0;
+        int rc = vrt_host_alloc(c, px * sizeof(float4), (void**)&c->stage_rgba);
+        if (rc) return rc;
+        rc = vrt_host_alloc(c, px * sizeof(int32_t), (void**)&c->stage_hit);
+        if (rc) return rc;
+        c->stage_px = px;
+    }
+    const int n_bands = VRT_STAGED_BANDS, n_thr = VRT_STAGED_THREADS;
+    const int band = (int)(((H + n_bands - 1) / n_bands + 7) & ~(size_t)7);
+    const int n_parts = (int)((H + band - 1) / band);
+    vrt_params q = *p;
+    q.tile_rows = band; q.tile_index = 0; q.tile_count = 1;
+    q.n_record_pixels = 0; q.record_pixels = nullptr;
+    int rc = vrt_render_begin_parts(c, &q, c->stage_rgba, hit_id_out ? c->stage_hit : nullptr, n_parts);
+    if (rc) return rc;
+    // A band is traced in less time than one thread needs to copy it out, so a helper thread takes
+    // the odd bands and this one the even ones; each waits for its band's event first.
+    hipError_t err[VRT_STAGED_THREADS] = {};
+    auto copy_bands = [&](int first) {
+        if (first >= 1 && hipSetDevice(c->device) != hipSuccess) { err[first] = hipErrorInvalidDevice; return; }
+        for (int k = first; k < n_parts; k += n_thr) {
+            const hipError_t e = hipEventSynchronize(c->part_ev[k]);
+            if (e != hipSuccess) { err[first] = e; return; }
+            const size_t r0 = (size_t)k * band, r1 = r0 + band < H ? r0 + band : H;
+            memcpy(rgba_out + r0 * W * 4, c->stage_rgba + r0 * W * 4, (r1 - r0) * W * sizeof(float4));
+            if (hit_id_out) memcpy(hit_id_out + r0 * W, c->stage_hit + r0 * W, (r1 - r0) * W * sizeof(int32_t));
+        }
+    };
+    {
+        std::vector<std::thread> helpers;
+        for (int t = 1; t < n_thr && t < n_parts; ++t) helpers.emplace_back(copy_bands, t);
+        copy_bands(0);
+        for (auto& h : helpers) h.join();
+    }
+    for (int k = 0; k < VRT_STAGED_THREADS; ++k)
+        if (err[k] != hipSuccess) {
+            vrt_render_end(c, nullptr);
+            return fail(c, VRT_ERR_HIP, std::string("staged frame: ") + hipGetErrorString(err[k]));
+        }
+    return vrt_render_end(c, stats_out);
+}
+
 extern "C" int vrt_render(vrt_ctx* c, const vrt_params* p, float* rgba_out, int32_t* hit_id_out, vrt_stats* stats_out)
 {
     if (!c || !p || !rgba_out) return fail(c, VRT_ERR_INVALID, "null argument");
     if (p->n_record_pixels < 0 || (p->n_record_pixels > 0 && (!p->record_pixels || !p->record_count_out)))
         return fail(c, VRT_ERR_INVALID, "record arguments missing");
     if (c->multi) return vrt_multi_render(c, p, rgba_out, hit_id_out, stats_out);
+    if (!c->pending) {
+        const int rs = render_staged(c, p, rgba_out, hit_id_out, stats_out);
+        if (rs < 0) return rs;
+        if (rs == 0) {
+            if (p->n_record_pixels > 0) {
+                DevParams RP;
+                int rr = prepare(c, p, &RP);
+                if (rr) return rr;
+                return run_records(c, p, RP, p->record_pixels, p->n_record_pixels, p->record_cap, -1, p->record_out,
+                                   p->record_count_out, nullptr, nullptr, nullptr);
+            }
+            return VRT_OK;
+        }
+    }
     DevParams P;
     int rc = begin_frame(c, p, rgba_out, hit_id_out, &P);
     if (rc) return rc;

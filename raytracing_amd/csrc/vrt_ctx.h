@@ -29,6 +29,7 @@ struct VrtOptions {
     int slab_fma = 1;           // tree scenes: fused box test where the scene lies near enough to the origin for it (0: never)
     int stack_cap = 0;          // tests: traversal-stack entries per lane (0 = all the kernels have), forces the stackless finish
     int block_compact = 0;      // tree scenes, one child per hit: bounces compacted inside four-wave blocks (0: one wave per tile through all bounces)
+    int staged = 1;             // vrt_render into pageable memory goes through page-locked staging in bands
     int zero_copy = 1;          // frames into a vrt_host_alloc buffer are stored there by the frame kernel itself
     int fail_after_build = 0;   // tests: vrt_set_scene reports a failure after uploads and tree build have succeeded
 };
@@ -95,6 +96,8 @@ struct vrt_ctx {
     std::vector<std::pair<void*, size_t>> registered;
     std::vector<void*> host_allocs;            // page-locked buffers handed out by vrt_host_alloc
     std::vector<size_t> host_alloc_bytes;      // their sizes, same order
+    // page-locked staging of vrt_render for callers whose frame buffer the device cannot reach (pageable memory)
+    float* stage_rgba = nullptr; int32_t* stage_hit = nullptr; size_t stage_px = 0;
     // wavefront workspace
     WfWorkspace wf; bool wf_two = false; bool wf_short = false;
     // the device's copy of the library's static scratch array (vrt_render_device_noalloc) and the

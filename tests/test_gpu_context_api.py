@@ -271,3 +271,39 @@ def test_frames_stored_straight_into_page_locked_buffers(vrt_ctx):
     finally:
         vrt_ctx.set_option("zero_copy", 1)
         vrt_ctx.host_free(big)
+
+
+def test_frames_into_pageable_memory_go_through_staging(vrt_ctx, oracle_mod):
+    """vrt_render into an array the device cannot reach renders bands into page-locked staging and
+    copies each out while the next is traced (frames of 2^18 pixels and more).  Same frame, hit
+    ids, ray counts and recorded segments as the runtime's own pageable copy (option staged off),
+    for a height that is no multiple of the band height; parameter errors are reported alike."""
+    scene, cam, _ = _spheres(648, 483)
+    kw = dict(spp=1, seed=3, max_depth=4, rng=200.0)
+    vrt_ctx.set_scene(scene)
+    vrt_ctx.set_camera(cam)
+    px = np.array([5, 70_000, 200_123, 648 * 483 - 1], np.int32)
+    out = {}
+    for staged in (1, 0):
+        vrt_ctx.set_option("staged", staged)
+        try:
+            prm = ra.Params(**kw)
+            segs, counts = prm.record(px, cap=32)
+            rgba = np.full((cam.height, cam.width, 4), -5.0, np.float32)
+            hit = np.full((cam.height, cam.width), -5, np.int32)
+            _, _, st = vrt_ctx.render(prm, rgba=rgba, hit=hit)
+            out[staged] = (rgba, hit, list(st.rays), st.pixels, np.array(counts), bytes(segs))
+            only = np.full_like(rgba, -5.0)
+            vrt_ctx.render(ra.Params(**kw), rgba=only, hit=None, want_hit=False)
+            assert np.array_equal(only, rgba, equal_nan=True)
+            with pytest.raises(host.VrtError) as e:
+                vrt_ctx.render(ra.Params(**dict(kw, spp=0)), rgba=rgba, hit=hit)
+            assert e.value.code == abi.VRT_ERR_INVALID
+        finally:
+            vrt_ctx.set_option("staged", 1)
+    a, b = out[1], out[0]
+    assert np.array_equal(a[0], b[0], equal_nan=True) and np.array_equal(a[1], b[1])
+    assert a[2] == b[2] and a[3] == b[3] == cam.width * cam.height
+    assert np.array_equal(a[4], b[4]) and a[5] == b[5]
+    o_rgba, o_hit, o_rays = oracle_mod.render(scene, cam, ra.Params(**kw).c, n_threads=8)
+    assert np.array_equal(a[1], o_hit) and np.array_equal(np.array(a[2], np.uint64), o_rays)
