@@ -609,7 +609,7 @@ def main():
             ctx.host_free(p_rgba)
             h_rgba = np.zeros((H, W, 4), np.float32)
             h_hit = np.zeros((H, W), np.int32)
-            pageable = host_ms(h_rgba, h_hit, min(n_host, 5))
+            pageable = host_ms(h_rgba, h_hit, min(n_host, 15))
             out["host_buffer_path"] = {
                 "what": "vrt_render incl. device-to-host copy of the frame (16 B/pixel) and the hit ids (4 B/pixel)",
                 "ms_per_frame_page_locked": out["ms_per_frame_host"],
