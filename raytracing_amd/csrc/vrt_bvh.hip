@@ -434,53 +434,85 @@ __global__ __launch_bounds__(256) void k_collapse4_level(const float4* __restric
 struct SahTask { int b, e, idx, parent; };
 #define VRT_SAH_NB 16
 
-__device__ __forceinline__ float sah_wave_min(float v)
+// Minimum / maximum over the G lanes of a group (G = 64: the wave).
+template <int G>
+__device__ __forceinline__ float sah_group_min(float v)
 {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    for (int o = G / 2; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
     return v;
 }
-__device__ __forceinline__ float sah_wave_max(float v)
+template <int G>
+__device__ __forceinline__ float sah_group_max(float v)
 {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    for (int o = G / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
+__device__ __forceinline__ float sah_wave_min(float v) { return sah_group_min<64>(v); }
+__device__ __forceinline__ float sah_wave_max(float v) { return sah_group_max<64>(v); }
 __device__ __forceinline__ float sah_area(const float lo[3], const float hi[3])
 {
     const float x = hi[0] - lo[0], y = hi[1] - lo[1], z = hi[2] - lo[2];
     return x < 0.f ? 0.f : x * y + y * z + z * x;
 }
 
+// Tasks of at most VRT_SAH_SMALL primitives are split by groups of 16 lanes, four to a wave: near
+// the leaves a level of the 1 M-triangle build has 250 000 nodes of two to eight primitives, and
+// a wave each left 56 and more of its lanes idle (5 of the build's 11 ms).
+#define VRT_SAH_SMALL 32
+
+// Appends a child task to the queue of its size class.  counts: [0] wave-sized, [3] small.
+// (One atomic per call on a counter the whole chip shares: fine for the few large tasks of
+// k_big_finish; k_sah_level claims its slots once per block.)
+__device__ __forceinline__ void sah_push_child(int b, int e, int idx, int parent, SahTask* __restrict__ out_q,
+                                               SahTask* __restrict__ out_small, int* __restrict__ counts)
+{
+    const bool small = e - b <= VRT_SAH_SMALL;
+    SahTask* q = (small ? out_small : out_q) + atomicAdd(&counts[small ? 3 : 0], 1);
+    q->b = b; q->e = e; q->idx = idx; q->parent = parent;
+}
+
+// G lanes per task (64 or 16), 256 / G tasks per block.
+template <int G>
 __global__ __launch_bounds__(256) void k_sah_level(int level, const float4* __restrict__ in, float4* __restrict__ out,
                                                    const SahTask* __restrict__ in_q, int n_in,
-                                                   SahTask* __restrict__ out_q, int* __restrict__ out_count,
+                                                   SahTask* __restrict__ out_q, SahTask* __restrict__ out_small,
+                                                   int* __restrict__ counts,
                                                    float4* __restrict__ nodes, int* __restrict__ parent,
                                                    int* __restrict__ leaf_parent)
 {
-    // per wave: 3 axes x 16 bins x (count, lo[3], hi[3]) and two words for the ids of one-primitive children
-    __shared__ unsigned s_bins[4][3 * VRT_SAH_NB * 7 + 2];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int t = blockIdx.x * 4 + wave;
-    if (t >= n_in) return;   // whole waves leave
-    const SahTask task = in_q[t];
+    // per group: 3 axes x 16 bins x (count, lo[3], hi[3]) and two words for the ids of one-primitive children
+    __shared__ unsigned s_bins[256 / G][3 * VRT_SAH_NB * 7 + 2];
+    // Queue slots for the children are claimed once per block: an atomic on one address is served
+    // in about 9 ns whoever issues it, and a level near the leaves has 250 000 tasks.
+    __shared__ int s_want[2], s_base[2];   // [0] wave-sized children, [1] small ones
+    const int grp = threadIdx.x / G, lane = threadIdx.x % G;
+    const int shift = (threadIdx.x & 63) & ~(G - 1);                 // first lane of the group within its wave
+    const unsigned long long gmask = G == 64 ? ~0ull : (((1ull << (G & 63)) - 1ull) << shift);
+    const int t = blockIdx.x * (256 / G) + grp;
+    if (threadIdx.x < 2) s_want[threadIdx.x] = 0;
+    __syncthreads();
+    const bool have = t < n_in;   // groups without a task only take part in the block's barriers
+    SahTask task = {0, 0, 0, -1};
+    if (have) task = in_q[t];
     const int b = task.b, e = task.e, idx = task.idx, m = e - b;
-    unsigned* bins = s_bins[wave];
-    if (lane == 0) parent[idx] = task.parent;
+    unsigned* bins = s_bins[grp];
+    if (have && lane == 0) parent[idx] = task.parent;
 
     // 1. centroid bounds
     float cl[3] = {INFINITY, INFINITY, INFINITY}, ch[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int i = b + lane; i < e; i += 64) {
+    for (int i = b + lane; i < e; i += G) {
         const float4 lo = in[2 * (size_t)i], hi = in[2 * (size_t)i + 1];
         const float c[3] = {0.5f * (lo.x + hi.x), 0.5f * (lo.y + hi.y), 0.5f * (lo.z + hi.z)};
         for (int k = 0; k < 3; ++k) { cl[k] = fminf(cl[k], c[k]); ch[k] = fmaxf(ch[k], c[k]); }
     }
-    for (int k = 0; k < 3; ++k) { cl[k] = sah_wave_min(cl[k]); ch[k] = sah_wave_max(ch[k]); }
+    for (int k = 0; k < 3; ++k) { cl[k] = sah_group_min<G>(cl[k]); ch[k] = sah_group_max<G>(ch[k]); }
 
     // 2. bins
     int best_axis = -1, best_bin = 0;
     if (level < 48 && (ch[0] > cl[0] || ch[1] > cl[1] || ch[2] > cl[2])) {
-        for (int w = lane; w < 3 * VRT_SAH_NB * 7; w += 64) {
+        for (int w = lane; w < 3 * VRT_SAH_NB * 7; w += G) {
             const int f = w % 7;
             bins[w] = f == 0 ? 0u : (f <= 3 ? 0xffffffffu : 0u);   // count, lo (min), hi (max) as ordered uints
         }
@@ -488,7 +520,7 @@ __global__ __launch_bounds__(256) void k_sah_level(int level, const float4* __re
         __builtin_amdgcn_wave_barrier();
         float scale[3];
         for (int k = 0; k < 3; ++k) scale[k] = ch[k] > cl[k] ? VRT_SAH_NB / (ch[k] - cl[k]) : 0.f;
-        for (int i = b + lane; i < e; i += 64) {
+        for (int i = b + lane; i < e; i += G) {
             const float4 lo = in[2 * (size_t)i], hi = in[2 * (size_t)i + 1];
             const float c[3] = {0.5f * (lo.x + hi.x), 0.5f * (lo.y + hi.y), 0.5f * (lo.z + hi.z)};
             const float l3[3] = {lo.x, lo.y, lo.z}, h3[3] = {hi.x, hi.y, hi.z};
@@ -503,7 +535,7 @@ __global__ __launch_bounds__(256) void k_sah_level(int level, const float4* __re
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        // 3. lanes 0..2 sweep one axis each
+        // 3. lanes 0..2 of the group sweep one axis each
         float my_cost = INFINITY;
         int my_bin = 0;
         if (lane < 3 && ch[lane] > cl[lane]) {
@@ -532,8 +564,8 @@ __global__ __launch_bounds__(256) void k_sah_level(int level, const float4* __re
         // the first axis with the smallest cost, as the host build picks it
         float best = INFINITY;
         for (int k = 0; k < 3; ++k) {
-            const float ck = __shfl(my_cost, k, 64);
-            const int bk = __shfl(my_bin, k, 64);
+            const float ck = __shfl(my_cost, shift + k, 64);
+            const int bk = __shfl(my_bin, shift + k, 64);
             if (ck < best) { best = ck; best_axis = k; best_bin = bk; }
         }
     }
@@ -550,11 +582,11 @@ __global__ __launch_bounds__(256) void k_sah_level(int level, const float4* __re
     };
     int n_left = 0;
     if (best_axis >= 0) {
-        for (int base = 0; base < m; base += 64) {
+        for (int base = 0; base < m; base += G) {
             const int i = b + base + lane;
             bool p = false;
             if (i < e) p = goes_left(in[2 * (size_t)i], in[2 * (size_t)i + 1], i);
-            n_left += __popcll(__ballot(p));
+            n_left += __popcll(__ballot(p) & gmask);
         }
     }
     const bool by_index = best_axis < 0 || n_left == 0 || n_left == m;   // no usable split: halve by index
@@ -562,7 +594,7 @@ __global__ __launch_bounds__(256) void k_sah_level(int level, const float4* __re
     float llo[3] = {INFINITY, INFINITY, INFINITY}, lhi[3] = {-INFINITY, -INFINITY, -INFINITY};
     float rlo[3] = {INFINITY, INFINITY, INFINITY}, rhi[3] = {-INFINITY, -INFINITY, -INFINITY};
     int off_l = 0, off_r = 0;
-    for (int base = 0; base < m; base += 64) {
+    for (int base = 0; base < m; base += G) {
         const int i = b + base + lane;
         const bool valid = i < e;
         float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
@@ -571,10 +603,10 @@ __global__ __launch_bounds__(256) void k_sah_level(int level, const float4* __re
             lo = in[2 * (size_t)i]; hi = in[2 * (size_t)i + 1];
             p = by_index ? (i - b) < n_left : goes_left(lo, hi, i);
         }
-        const unsigned long long ml = __ballot(valid && p), mr = __ballot(valid && !p);
+        const unsigned long long ml = __ballot(valid && p) & gmask, mr = __ballot(valid && !p) & gmask;
         if (valid) {
-            const unsigned long long mine = p ? ml : mr;
-            const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mine >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mine, 0u));
+            const unsigned long long mine = (p ? ml : mr) >> shift;   // the group's lanes from bit 0
+            const int rank = __popcll(mine & ((1ull << lane) - 1ull));
             const int dest = p ? b + off_l + rank : b + n_left + off_r + rank;
             out[2 * (size_t)dest] = lo; out[2 * (size_t)dest + 1] = hi;
             const float l3[3] = {lo.x, lo.y, lo.z}, h3[3] = {hi.x, hi.y, hi.z};
@@ -587,16 +619,25 @@ __global__ __launch_bounds__(256) void k_sah_level(int level, const float4* __re
         off_l += __popcll(ml); off_r += __popcll(mr);
     }
     for (int a = 0; a < 3; ++a) {
-        llo[a] = sah_wave_min(llo[a]); lhi[a] = sah_wave_max(lhi[a]);
-        rlo[a] = sah_wave_min(rlo[a]); rhi[a] = sah_wave_max(rhi[a]);
+        llo[a] = sah_group_min<G>(llo[a]); lhi[a] = sah_group_max<G>(lhi[a]);
+        rlo[a] = sah_group_min<G>(rlo[a]); rhi[a] = sah_group_max<G>(rhi[a]);
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
     // 5. the node and its children
-    if (lane == 0) {
-        const int n_right = m - n_left;
-        const int idx_l = idx + 1, idx_r = idx + n_left;
+    const int n_right = m - n_left;
+    const int idx_l = idx + 1, idx_r = idx + n_left;
+    const bool small_l = n_left <= VRT_SAH_SMALL, small_r = n_right <= VRT_SAH_SMALL;
+    int at_l = 0, at_r = 0;   // the children's places among the block's new tasks of their class
+    if (have && lane == 0) {
+        if (n_left > 1) at_l = atomicAdd(&s_want[small_l ? 1 : 0], 1);
+        if (n_right > 1) at_r = atomicAdd(&s_want[small_r ? 1 : 0], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) s_base[threadIdx.x] = s_want[threadIdx.x] ? atomicAdd(&counts[threadIdx.x ? 3 : 0], s_want[threadIdx.x]) : 0;
+    __syncthreads();
+    if (have && lane == 0) {
         int c0, c1;
         if (n_left == 1) { const int id = (int)bins[3 * VRT_SAH_NB * 7]; c0 = ~id; leaf_parent[id] = idx; } else c0 = idx_l;
         if (n_right == 1) { const int id = (int)bins[3 * VRT_SAH_NB * 7 + 1]; c1 = ~id; leaf_parent[id] = idx; } else c1 = idx_r;
@@ -605,11 +646,13 @@ __global__ __launch_bounds__(256) void k_sah_level(int level, const float4* __re
         nd[1] = make_float4(lhi[1], lhi[2], rlo[0], rlo[1]);
         nd[2] = make_float4(rlo[2], rhi[0], rhi[1], rhi[2]);
         nd[3] = make_float4(__int_as_float(c0), __int_as_float(c1), 0.f, 0.f);
-        const int n_new = (n_left > 1) + (n_right > 1);
-        if (n_new) {
-            int at = atomicAdd(out_count, n_new);
-            if (n_left > 1) { SahTask q = {b, b + n_left, idx_l, idx}; out_q[at++] = q; }
-            if (n_right > 1) { SahTask q = {b + n_left, e, idx_r, idx}; out_q[at] = q; }
+        if (n_left > 1) {
+            const SahTask q = {b, b + n_left, idx_l, idx};
+            (small_l ? out_small : out_q)[s_base[small_l ? 1 : 0] + at_l] = q;
+        }
+        if (n_right > 1) {
+            const SahTask q = {b + n_left, e, idx_r, idx};
+            (small_r ? out_small : out_q)[s_base[small_r ? 1 : 0] + at_r] = q;
         }
     }
 }
@@ -871,16 +914,25 @@ __global__ __launch_bounds__(256) void k_big_scatter(const float4* __restrict__ 
         llo[a] = sah_wave_min(llo[a]); lhi[a] = sah_wave_max(lhi[a]); rlo[a] = sah_wave_min(rlo[a]); rhi[a] = sah_wave_max(rhi[a]);
         lcl[a] = sah_wave_min(lcl[a]); lch[a] = sah_wave_max(lch[a]); rcl[a] = sah_wave_min(rcl[a]); rch[a] = sah_wave_max(rch[a]);
     }
+    // the block's four waves meet in LDS first: the 24 words of a task share two cache lines, and
+    // atomics on one line are served one after the other for the whole chip
+    __shared__ unsigned s_out[24];
+    if (threadIdx.x < 24) s_out[threadIdx.x] = 0u;
+    __syncthreads();
     if ((threadIdx.x & 63) == 0) {
-        BigOut& O = outs[t];
         if (wave_l) for (int a = 0; a < 3; ++a) {
-            atomicMax(&O.box[a], ~enc_f(llo[a])); atomicMax(&O.box[3 + a], enc_f(lhi[a]));
-            atomicMax(&O.cen[a], ~enc_f(lcl[a])); atomicMax(&O.cen[3 + a], enc_f(lch[a]));
+            atomicMax(&s_out[a], ~enc_f(llo[a])); atomicMax(&s_out[3 + a], enc_f(lhi[a]));
+            atomicMax(&s_out[12 + a], ~enc_f(lcl[a])); atomicMax(&s_out[15 + a], enc_f(lch[a]));
         }
         if (wave_r) for (int a = 0; a < 3; ++a) {
-            atomicMax(&O.box[6 + a], ~enc_f(rlo[a])); atomicMax(&O.box[9 + a], enc_f(rhi[a]));
-            atomicMax(&O.cen[6 + a], ~enc_f(rcl[a])); atomicMax(&O.cen[9 + a], enc_f(rch[a]));
+            atomicMax(&s_out[6 + a], ~enc_f(rlo[a])); atomicMax(&s_out[9 + a], enc_f(rhi[a]));
+            atomicMax(&s_out[18 + a], ~enc_f(rcl[a])); atomicMax(&s_out[21 + a], enc_f(rch[a]));
         }
+    }
+    __syncthreads();
+    if (threadIdx.x < 24 && s_out[threadIdx.x]) {
+        BigOut& O = outs[t];
+        atomicMax(threadIdx.x < 12 ? &O.box[threadIdx.x] : &O.cen[threadIdx.x - 12], s_out[threadIdx.x]);
     }
 }
 
@@ -889,7 +941,8 @@ __global__ __launch_bounds__(256) void k_big_scatter(const float4* __restrict__ 
 __global__ __launch_bounds__(64) void k_big_finish(int n_big, const BigTask* __restrict__ tasks, const BigSplit* __restrict__ split,
                                                    const BigOut* __restrict__ outs, float4* __restrict__ nodes,
                                                    int* __restrict__ parent, int* __restrict__ leaf_parent,
-                                                   SahTask* __restrict__ out_q, int* __restrict__ counts,
+                                                   SahTask* __restrict__ out_q, SahTask* __restrict__ out_small,
+                                                   int* __restrict__ counts,
                                                    BigTask* __restrict__ next_tasks, int* __restrict__ next_chunk_task)
 {
     const int t = blockIdx.x * 64 + threadIdx.x;
@@ -923,8 +976,7 @@ __global__ __launch_bounds__(64) void k_big_finish(int n_big, const BigTask* __r
             N->cb[3] = cs[3]; N->cb[4] = cs[4]; N->cb[5] = cs[5];
             for (int j = 0; j < n_chunks; ++j) next_chunk_task[chunk0 + j] = nt;
         } else {
-            SahTask* q = out_q + atomicAdd(&counts[0], 1);
-            q->b = b; q->e = e; q->idx = child_idx; q->parent = idx;
+            sah_push_child(b, e, child_idx, idx, out_q, out_small, counts);
         }
     }
 }
@@ -1102,8 +1154,9 @@ static hipError_t build_sah_device(int n, const float4* d_pbox, const unsigned* 
                                    int* d_leaf_parent, hipStream_t stream)
 {
     float4 *ref_a = nullptr, *ref_b = nullptr;
-    SahTask *q_a = nullptr, *q_b = nullptr;
-    int* counts = nullptr;   // next level: small tasks, large tasks, chunks of the large tasks
+    SahTask *q_a = nullptr, *q_b = nullptr;     // tasks a wave splits
+    SahTask *qs_a = nullptr, *qs_b = nullptr;   // tasks of at most VRT_SAH_SMALL primitives, four to a wave
+    int* counts = nullptr;   // next level: wave-sized tasks, large tasks, chunks of the large tasks, small tasks
     // large tasks (more than VRT_SAH_BIG primitives, so at most n / VRT_SAH_BIG per level) and their chunks
     const int max_big = n / VRT_SAH_BIG + 2, max_chunks = n / VRT_SAH_CHUNK + max_big + 2;
     BigTask *big_a = nullptr, *big_b = nullptr;
@@ -1118,7 +1171,9 @@ static hipError_t build_sah_device(int n, const float4* d_pbox, const unsigned* 
     SCHK(hipMalloc(&ref_b, 2 * (size_t)n * sizeof(float4)));
     SCHK(hipMalloc(&q_a, (size_t)n * sizeof(SahTask)));
     SCHK(hipMalloc(&q_b, (size_t)n * sizeof(SahTask)));
-    SCHK(hipMalloc(&counts, 3 * sizeof(int)));
+    SCHK(hipMalloc(&qs_a, (size_t)n * sizeof(SahTask)));
+    SCHK(hipMalloc(&qs_b, (size_t)n * sizeof(SahTask)));
+    SCHK(hipMalloc(&counts, 4 * sizeof(int)));
     SCHK(hipMalloc(&big_a, (size_t)max_big * sizeof(BigTask)));
     SCHK(hipMalloc(&big_b, (size_t)max_big * sizeof(BigTask)));
     SCHK(hipMalloc(&chunk_a, (size_t)max_chunks * sizeof(int)));
@@ -1128,18 +1183,18 @@ static hipError_t build_sah_device(int n, const float4* d_pbox, const unsigned* 
     SCHK(hipMalloc(&level_state, state_bytes));
     hipLaunchKernelGGL(k_sah_refs, dim3((n + 255) / 256), dim3(256), 0, stream, n, d_pbox, ref_a);
     {
-        int n_in = 0, n_big = 0, n_chunks = 0;
+        int n_in = 0, n_big = 0, n_chunks = 0, n_small = 0;
         if (n > VRT_SAH_BIG) {
             n_big = 1; n_chunks = (n + VRT_SAH_CHUNK - 1) / VRT_SAH_CHUNK;
             hipLaunchKernelGGL(k_big_root, dim3((n_chunks + 255) / 256), dim3(256), 0, stream, n, d_cb, big_a, chunk_a);
         } else {
             const SahTask root = {0, n, 0, -1};
-            SCHK(hipMemcpyAsync(q_a, &root, sizeof root, hipMemcpyHostToDevice, stream));
-            n_in = 1;
+            SCHK(hipMemcpyAsync(n <= VRT_SAH_SMALL ? qs_a : q_a, &root, sizeof root, hipMemcpyHostToDevice, stream));
+            if (n <= VRT_SAH_SMALL) n_small = 1; else n_in = 1;
         }
-        for (int level = 0; (n_in > 0 || n_big > 0) && level < 4096; ++level) {
-            int h[3] = {0, 0, 0};
-            SCHK(hipMemsetAsync(counts, 0, 3 * sizeof(int), stream));
+        for (int level = 0; (n_in > 0 || n_big > 0 || n_small > 0) && level < 4096; ++level) {
+            int h[4] = {0, 0, 0, 0};
+            SCHK(hipMemsetAsync(counts, 0, 4 * sizeof(int), stream));
             if (n_big > 0) {
                 if (n_big > max_big || n_chunks > max_chunks) { e = hipErrorUnknown; goto sah_done; }   // cannot happen: tasks are disjoint ranges
                 unsigned* bins = level_state;
@@ -1151,24 +1206,28 @@ static hipError_t build_sah_device(int n, const float4* d_pbox, const unsigned* 
                 hipLaunchKernelGGL(k_big_scatter, dim3(n_chunks), dim3(256), 0, stream, ref_a, ref_b, big_a, chunk_a, split,
                                    left_count, outs);
                 hipLaunchKernelGGL(k_big_finish, dim3((n_big + 63) / 64), dim3(64), 0, stream, n_big, big_a, split, outs, d_nodes,
-                                   d_parent, d_leaf_parent, q_b, counts, big_b, chunk_b);
+                                   d_parent, d_leaf_parent, q_b, qs_b, counts, big_b, chunk_b);
             }
             if (n_in > 0)
-                hipLaunchKernelGGL(k_sah_level, dim3((n_in + 3) / 4), dim3(256), 0, stream, level, ref_a, ref_b, q_a, n_in, q_b,
-                                   counts, d_nodes, d_parent, d_leaf_parent);
-            SCHK(hipMemcpyAsync(h, counts, 3 * sizeof(int), hipMemcpyDeviceToHost, stream));
+                hipLaunchKernelGGL((k_sah_level<64>), dim3((n_in + 3) / 4), dim3(256), 0, stream, level, ref_a, ref_b, q_a, n_in, q_b,
+                                   qs_b, counts, d_nodes, d_parent, d_leaf_parent);
+            if (n_small > 0)
+                hipLaunchKernelGGL((k_sah_level<16>), dim3((n_small + 15) / 16), dim3(256), 0, stream, level, ref_a, ref_b, qs_a,
+                                   n_small, q_b, qs_b, counts, d_nodes, d_parent, d_leaf_parent);
+            SCHK(hipMemcpyAsync(h, counts, 4 * sizeof(int), hipMemcpyDeviceToHost, stream));
             SCHK(hipStreamSynchronize(stream));
-            n_in = h[0]; n_big = h[1]; n_chunks = h[2];
+            n_in = h[0]; n_big = h[1]; n_chunks = h[2]; n_small = h[3];
             float4* tr = ref_a; ref_a = ref_b; ref_b = tr;
             SahTask* tq = q_a; q_a = q_b; q_b = tq;
+            tq = qs_a; qs_a = qs_b; qs_b = tq;
             BigTask* tb = big_a; big_a = big_b; big_b = tb;
             int* tc = chunk_a; chunk_a = chunk_b; chunk_b = tc;
         }
-        if (n_in > 0 || n_big > 0) e = hipErrorUnknown;
+        if (n_in > 0 || n_big > 0 || n_small > 0) e = hipErrorUnknown;
     }
 sah_done:
 #undef SCHK
-    hipFree(ref_a); hipFree(ref_b); hipFree(q_a); hipFree(q_b); hipFree(counts);
+    hipFree(ref_a); hipFree(ref_b); hipFree(q_a); hipFree(q_b); hipFree(qs_a); hipFree(qs_b); hipFree(counts);
     hipFree(big_a); hipFree(big_b); hipFree(chunk_a); hipFree(chunk_b); hipFree(left_count); hipFree(split); hipFree(level_state);
     return e;
 }
