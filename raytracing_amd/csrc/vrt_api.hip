@@ -84,6 +84,7 @@ static void options_from_env(VrtOptions& o)
     o.packet = (int)geti("VRT_PACKET", -1);
     o.block_compact = (int)geti("VRT_BLOCK_COMPACT", 0);
     o.zero_copy = (int)geti("VRT_ZERO_COPY", 1);
+    o.tile_sort = (int)geti("VRT_TILE_SORT", 1);
     o.staged = (int)geti("VRT_STAGED", 1);
     o.quad_max = (int)geti("VRT_QUAD_MAX", -1);
     o.beam = (int)geti("VRT_BEAM", -1);
@@ -108,6 +109,7 @@ extern "C" int vrt_set_option(vrt_ctx* c, const char* name, long long value)
     else if (n == "no_big") o.no_big = value != 0;
     else if (n == "block_compact") o.block_compact = value != 0;
     else if (n == "zero_copy") o.zero_copy = value != 0;
+    else if (n == "tile_sort") o.tile_sort = value != 0;
     else if (n == "staged") o.staged = value != 0;
     else if (n == "slab_fma") o.slab_fma = value != 0;
     else if (n == "stack_cap") { if (value < 0 || value > VRT_TRAV_STACK) return fail(c, VRT_ERR_INVALID, "stack_cap: 0..VRT_TRAV_STACK"); o.stack_cap = (int)value; }
@@ -156,6 +158,7 @@ static void teardown(vrt_ctx* c)
     hipFree(c->d_ctr); hipFree(c->d_ctr_ring); hipFree(c->d_rgba); hipFree(c->d_hit);
     hipFree(c->d_rec_pixels); hipFree(c->d_segs); hipFree(c->d_seg_counts);
     hipFree(c->d_px_rgba); hipFree(c->d_px_hit);
+    hipFree(c->d_tile_cost); hipFree(c->d_tile_keys); hipFree(c->d_tile_iota); hipFree(c->d_tile_order); hipFree(c->d_tile_tmp);
     if (c->static_stage) hipHostFree(c->static_stage);
     for (auto& r : c->registered) { void* base; size_t len; page_range(r.first, r.second, &base, &len); hipHostUnregister(base); }
     c->registered.clear();
@@ -579,6 +582,7 @@ int vrt_swap_scene_one(vrt_ctx* c, SceneBufs& nb)
     c->sb = std::move(nb);
     nb = SceneBufs();
     c->have_scene = true;
+    c->scene_gen++;
     return VRT_OK;
 }
 
@@ -797,9 +801,63 @@ static int ensure_wf(vrt_ctx* c, size_t slots, bool two, hipStream_t stream)
 
 // Enqueues one frame on `stream`.  `ctr` = the counter block to count into (already clear), or
 // null for the path's own block, cleared here.
-static int enqueue_frame(vrt_ctx* c, const vrt_params* p, const DevParams& P, float4* rgba, int* hit,
-                         hipStream_t stream, unsigned long long* ctr = nullptr)
+// Tree scenes: the megakernel's tiles are dispatched most expensive first.  A launch keeps 79-93 %
+// of the chip's wave slots filled on the tree workloads; the rest is the tail, in which the last
+// tiles dispatched run alone, and its length is the duration of whatever those tiles are.  Costs
+// (clock ticks per tile) come from a frame of the same layout on the same scene: that frame runs
+// in tile order and reports them, a radix sort behind it on the same stream turns them into the
+// order (descending, ties by tile number), and the frames after it use the order; every 16th
+// refreshes it.  The camera is not part of the layout on purpose: a host that moves it a little
+// every frame still dispatches by the costs of a frame ago.  Nothing about a frame's result
+// depends on the order.  Returns with P.tile_order / P.tile_cost set (or left null) and *sort_after
+// telling the caller to enqueue the sort behind the frame.
+static int plan_tile_order(vrt_ctx* c, DevParams& P, hipStream_t stream, bool* sort_after, size_t* n_tiles)
 {
+    *sort_after = false;
+    const int pshift = 6 - P.sample_shift, pw_shift = (pshift + 1) >> 1;
+    const size_t bx = ((size_t)c->cam.width + ((size_t)1 << pw_shift) - 1) >> pw_shift;
+    const size_t by = ((size_t)P.local_rows + ((size_t)1 << (pshift - pw_shift)) - 1) >> (pshift - pw_shift);
+    const size_t n = bx * by;
+    *n_tiles = n;
+    if (n < 8192 || n > 0x7fffffffull) return VRT_OK;   // two rounds of waves: nothing to order
+    const long long sig[10] = {(long long)c->scene_gen, (long long)n, (long long)bx, P.spp, P.max_depth, P.sample_shift,
+                               ((long long)P.tile_index << 32) | (unsigned)P.tile_count, ((long long)P.tile_rows << 1) | (P.compact ? 1 : 0),
+                               (long long)P.flags, ((long long)c->cam.width << 32) | (unsigned)c->cam.height};
+    if (c->tile_stream && c->tile_stream != stream) {
+        // frames of another stream may still read the order this one is about to replace
+        HIPCHK(c, hipDeviceSynchronize());
+        c->tile_valid = false;
+    }
+    if (n > c->tile_cap) {
+        HIPCHK(c, hipDeviceSynchronize());
+        hipFree(c->d_tile_cost); hipFree(c->d_tile_keys); hipFree(c->d_tile_iota); hipFree(c->d_tile_order); hipFree(c->d_tile_tmp);
+        c->d_tile_cost = c->d_tile_keys = nullptr; c->d_tile_iota = c->d_tile_order = nullptr; c->d_tile_tmp = nullptr;
+        c->tile_cap = 0; c->tile_valid = false;
+        c->tile_tmp_bytes = vrt_tile_sort_bytes(n);
+        if (!c->tile_tmp_bytes) return VRT_OK;   // no sort, no order
+        HIPCHK(c, hipMalloc(&c->d_tile_cost, n * sizeof(unsigned)));
+        HIPCHK(c, hipMalloc(&c->d_tile_keys, n * sizeof(unsigned)));
+        HIPCHK(c, hipMalloc(&c->d_tile_iota, n * sizeof(int)));
+        HIPCHK(c, hipMalloc(&c->d_tile_order, n * sizeof(int)));
+        HIPCHK(c, hipMalloc(&c->d_tile_tmp, c->tile_tmp_bytes));
+        HIPCHK(c, vrt_fill_iota(c->d_tile_iota, n, stream));
+        c->tile_cap = n;
+    }
+    const bool same = c->tile_valid && memcmp(sig, c->tile_sig, sizeof sig) == 0;
+    if (same) P.tile_order = c->d_tile_order;
+    if (!same || (++c->tile_age & 15u) == 0) {
+        P.tile_cost = c->d_tile_cost;
+        *sort_after = true;
+        memcpy(c->tile_sig, sig, sizeof sig);
+    }
+    c->tile_stream = stream;
+    return VRT_OK;
+}
+
+static int enqueue_frame(vrt_ctx* c, const vrt_params* p, const DevParams& P_in, float4* rgba, int* hit,
+                         hipStream_t stream, unsigned long long* ctr = nullptr, bool may_order = true)
+{
+    DevParams P = P_in;
     const bool two = two_children(c, p);
     int mode = p->mode == VRT_MODE_WAVEFRONT ? VRT_MODE_WAVEFRONT : VRT_MODE_MEGAKERNEL;
     DevScene& S = c->sb.scene;
@@ -844,10 +902,22 @@ static int enqueue_frame(vrt_ctx* c, const vrt_params* p, const DevParams& P, fl
         S.dbg = ctr; c->last_ctr = ctr;
         S.stack_cap = c->opt.stack_cap > 0 ? c->opt.stack_cap : VRT_TRAV_STACK;
         const bool fused = fused_form(c, nullptr);
-        if (c->sb.use_bvh && !two && !P.xcd_remap && c->opt.block_compact)
+        if (c->sb.use_bvh && !two && !P.xcd_remap && c->opt.block_compact) {
             HIPCHK(c, VRT_LAUNCH(fused, vrt_launch_mega_blk, S, c->cam, P, rgba, hit, ctr, stream));
-        else
+        } else {
+            bool sort_after = false;
+            size_t n_tiles = 0;
+            if (may_order && c->opt.tile_sort && c->sb.use_bvh && !P.xcd_remap) {
+                int rc = plan_tile_order(c, P, stream, &sort_after, &n_tiles);
+                if (rc) return rc;
+            }
             HIPCHK(c, VRT_LAUNCH(fused, vrt_launch_mega, S, c->cam, P, c->sb.use_bvh, two, rgba, hit, ctr, stream));
+            if (sort_after) {
+                HIPCHK(c, vrt_tile_sort(c->d_tile_cost, c->d_tile_keys, c->d_tile_iota, c->d_tile_order, n_tiles, c->d_tile_tmp,
+                                        c->tile_tmp_bytes, stream));
+                c->tile_valid = true;
+            }
+        }
     }
     c->last_pixels = (uint64_t)P.local_rows * c->cam.width;
     c->last_mode = mode;
@@ -1170,7 +1240,7 @@ extern "C" int vrt_render_begin_parts(vrt_ctx* c, const vrt_params* p, float* rg
         DevParams P;
         rc = prepare(c, &q, &P);
         if (rc) return rc;
-        rc = enqueue_frame(c, &q, P, direct ? direct : c->d_rgba, hit_id_out ? c->d_hit : nullptr, c->stream, c->d_ctr);
+        rc = enqueue_frame(c, &q, P, direct ? direct : c->d_rgba, hit_id_out ? c->d_hit : nullptr, c->stream, c->d_ctr, false);   // parts differ in layout from call to call
         if (rc) return rc;
         pixels += c->last_pixels;
         if (k == n_parts - 1) HIPCHK(c, hipEventRecord(c->ev1, c->stream));
@@ -1296,7 +1366,7 @@ extern "C" int vrt_render_device_noalloc(vrt_ctx* c, const vrt_params* p, void* 
     HIPCHK(c, hipMemsetAsync(ctr, 0, kStaticCtrBytes, s));   // the array keeps the last call's counts
     c->timed = false;
     P.flags |= p->flags & VRT_OUT_LINEAR_RGB;
-    return enqueue_frame(c, p, P, (float4*)rgba_dev, (int*)hit_id_dev, s, ctr);
+    return enqueue_frame(c, p, P, (float4*)rgba_dev, (int*)hit_id_dev, s, ctr, false);   // ordering tiles would allocate
 }
 
 extern "C" int vrt_tonemap_device(vrt_ctx* c, const void* rgb_dev, void* rgba_dev, uint64_t n_pixels, void* stream)

@@ -1232,6 +1232,38 @@ sah_done:
     return e;
 }
 
+// ------------------------------------------------------------------ dispatch order of the frame kernel's tiles
+
+namespace {
+__global__ __launch_bounds__(256) void k_iota(int* __restrict__ out, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = (int)i;
+}
+} // namespace
+
+size_t vrt_tile_sort_bytes(size_t n)
+{
+    size_t bytes = 0;
+    unsigned* k = nullptr; int* v = nullptr;
+    if (rocprim::radix_sort_pairs_desc(nullptr, bytes, k, k, v, v, n, 0, 32, (hipStream_t)0) != hipSuccess) return 0;
+    return bytes ? bytes : 16;
+}
+
+hipError_t vrt_fill_iota(int* iota, size_t n, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_iota, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, iota, n);
+    return hipGetLastError();
+}
+
+hipError_t vrt_tile_sort(const unsigned* cost, unsigned* keys_tmp, const int* iota, int* order, size_t n, void* tmp,
+                         size_t tmp_bytes, hipStream_t stream)
+{
+    // a stable sort: tiles of equal cost keep their ascending order, so the result is deterministic
+    return rocprim::radix_sort_pairs_desc(tmp, tmp_bytes, cost, keys_tmp, iota, order, n, 0, 32, stream);
+}
+
 #define BCHK(expr) do { e = (expr); if (e != hipSuccess) goto done; } while (0)
 
 hipError_t vrt_build_lbvh(const DevScene& S, float4* nodes, float4* wide, int* depth_out, float* ms_out,

@@ -30,6 +30,7 @@ struct VrtOptions {
     int stack_cap = 0;          // tests: traversal-stack entries per lane (0 = all the kernels have), forces the stackless finish
     int block_compact = 0;      // tree scenes, one child per hit: bounces compacted inside four-wave blocks (0: one wave per tile through all bounces)
     int staged = 1;             // vrt_render into pageable memory goes through page-locked staging in bands
+    int tile_sort = 1;          // tree scenes, megakernel: tiles dispatched most expensive first, by the costs an earlier frame measured
     int zero_copy = 1;          // frames into a vrt_host_alloc buffer are stored there by the frame kernel itself
     int fail_after_build = 0;   // tests: vrt_set_scene reports a failure after uploads and tree build have succeeded
 };
@@ -96,6 +97,12 @@ struct vrt_ctx {
     std::vector<std::pair<void*, size_t>> registered;
     std::vector<void*> host_allocs;            // page-locked buffers handed out by vrt_host_alloc
     std::vector<size_t> host_alloc_bytes;      // their sizes, same order
+    // Dispatch order of the megakernel's tiles (tree scenes): costs a frame measured, the order
+    // sorted from them, and the frame layout both belong to.
+    unsigned* d_tile_cost = nullptr; unsigned* d_tile_keys = nullptr; int* d_tile_iota = nullptr; int* d_tile_order = nullptr;
+    void* d_tile_tmp = nullptr; size_t tile_cap = 0, tile_tmp_bytes = 0;
+    long long tile_sig[10] = {0}; bool tile_valid = false; hipStream_t tile_stream = nullptr; unsigned tile_age = 0;
+    unsigned long long scene_gen = 0;          // bumped by every scene swap
     // page-locked staging of vrt_render for callers whose frame buffer the device cannot reach (pageable memory)
     float* stage_rgba = nullptr; int32_t* stage_hit = nullptr; size_t stage_px = 0;
     // wavefront workspace

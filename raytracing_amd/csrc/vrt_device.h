@@ -97,6 +97,8 @@ struct DevParams {
     int general;      // the scene or the flags need the general kernels: two children per hit, matte / transparent materials
     int quad_max;     // tree scenes: a wave with at most this many queries traces them four lanes per ray (0 = never)
     int beam;         // tree scenes, megakernel: the camera rays of a wave collect their candidate leaves together first
+    const int* tile_order;   // megakernel: block b renders tile tile_order[b] (null: tile b)
+    unsigned* tile_cost;     // megakernel: per tile, the clock ticks its wave ran (null: not recorded)
 };
 
 // Per-call ray counters: 256 slots x 8 words to spread atomic traffic, summed by the host.

@@ -72,5 +72,12 @@ namespace vrt_fused { VRT_LAUNCHERS }
 hipError_t vrt_build_lbvh(const DevScene& S, float4* nodes, float4* wide, int* depth_out, float* ms_out,
                           int builder, bool parity_collapse, hipStream_t stream);
 
+// Dispatch order of the megakernel's tiles: order[k] = the tile with the k-th largest cost (ties by
+// tile number).  iota = 0..n-1 (vrt_fill_iota), keys_tmp = n words of scratch, tmp = vrt_tile_sort_bytes(n) bytes.
+size_t vrt_tile_sort_bytes(size_t n);
+hipError_t vrt_fill_iota(int* iota, size_t n, hipStream_t stream);
+hipError_t vrt_tile_sort(const unsigned* cost, unsigned* keys_tmp, const int* iota, int* order, size_t n, void* tmp,
+                         size_t tmp_bytes, hipStream_t stream);
+
 // process_color over n pixels: 3 floats in, 4 floats out.
 hipError_t vrt_launch_tonemap(const float* rgb, float4* rgba, size_t n, hipStream_t stream);

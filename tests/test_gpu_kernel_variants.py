@@ -325,3 +325,49 @@ def test_beam_gives_the_same_frame(vrt_ctx, vrt_opts, which, spp):
             got, got_hit, st = vrt_ctx.render(ra.Params(**kw))
             assert np.array_equal(got, ref, equal_nan=True) and np.array_equal(got_hit, ref_hit), (beam, flags)
             assert list(st.rays) == list(ref_st.rays), (beam, flags)
+
+
+def test_frames_do_not_depend_on_the_tile_order(vrt_ctx):
+    """Tree scenes dispatch the megakernel's tiles most expensive first, by the costs a frame of the
+    same layout measured (option tile_sort): the first frame of a layout runs in tile order and
+    reports costs, the next ones use the sorted order, every 16th refreshes it.  Frame, hit ids and
+    ray counts must be those of the plain tile order in every one of 40 consecutive frames, across
+    a camera move (same layout: the order of the old view is used), a scene swap, a strip of the
+    frame (another layout) and a frame on another stream."""
+    import torch
+    offs = host.sampler_table(abi.VRT_SAMPLER_JITTERED, 4, 5, 0.01, 0.01, seed=4)
+    kw = dict(spp=4, offsets=offs, seed=9, max_depth=4, rng=200.0)
+    scene = ra.random_spheres_scene(3000, seed=21)
+    cam_a, cam_b = ra.random_spheres_camera(520, 260), ra.random_spheres_camera(520, 260)
+    cam_b.origin[0] += 0.75
+    H, W = 260, 520
+    dev = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
+    hit = torch.empty((H, W), dtype=torch.int32, device="cuda")
+    side = torch.cuda.Stream()
+
+    def frames(sort):
+        vrt_ctx.set_option("tile_sort", sort)
+        out = []
+        vrt_ctx.set_scene(scene)
+        for step in range(40):
+            if step == 0: vrt_ctx.set_camera(cam_a)
+            if step == 20: vrt_ctx.set_camera(cam_b)
+            if step == 30: vrt_ctx.set_scene(ra.random_spheres_scene(2500, seed=22))
+            prm = ra.Params(**kw) if step % 7 != 5 else ra.Params(tile_index=1, tile_count=2, tile_rows=8, **kw)
+            stream = side if step == 33 else torch.cuda.current_stream()
+            dev.fill_(-1.0); hit.fill_(-9)
+            torch.cuda.synchronize()
+            vrt_ctx.render_device(prm, dev.data_ptr(), hit.data_ptr(), stream.cuda_stream)
+            torch.cuda.synchronize()
+            st = vrt_ctx.fetch_stats()
+            out.append((dev.cpu().numpy().copy(), hit.cpu().numpy().copy(), list(st.rays)))
+        return out
+
+    try:
+        ref, got = frames(0), frames(1)
+    finally:
+        vrt_ctx.set_option("tile_sort", 1)
+    for step, (a, b) in enumerate(zip(ref, got)):
+        assert np.array_equal(a[0], b[0], equal_nan=True), step
+        assert np.array_equal(a[1], b[1]) and a[2] == b[2], step
+    assert ref[0][2] != ref[35][2]   # the scenes do differ
