@@ -342,6 +342,9 @@ def main():
                          "(0 = skip it)")
     ap.add_argument("--no-in-library-multi", action="store_true",
                     help="with N > 1: skip the measurement of vrt_create_multi (one process driving all N GPUs)")
+    ap.add_argument("--no-host-path", action="store_true",
+                    help="skip the vrt_render measurements into host memory (their frame kernels store over PCIe and "
+                         "would mix into a profiler's per-kernel averages)")
     ap.add_argument("--min-time", type=float, default=0.5,
                     help="the timed region of --steps steps is repeated until this many seconds are timed")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
@@ -586,7 +589,7 @@ def main():
             out["gathered_frame_equals_single_gpu_frame"] = frames_match
         if s8k is not None:
             out["scaling_8k"] = s8k
-        if world == 1:
+        if world == 1 and not args.no_host_path:
             # The boundary call itself: vrt_render with the frame delivered to host memory, i.e. the
             # `ms/frame` a Unity host sees.  Page-locked buffers of the library (vrt_host_alloc, what
             # the adapter gives PixelColorData) and, for reference, pageable numpy arrays.  Never `value`.
@@ -643,7 +646,7 @@ def main():
             rp = ra.Params(offsets=offsets, mode=mode, **kw)
             segs, counts = rp.record(px, cap=64)
             t0 = time.perf_counter()
-            ctx.render(rp, rgba=h_rgba, hit=h_hit)
+            ctx.render(rp, rgba=np.zeros((H, W, 4), np.float32), hit=np.zeros((H, W), np.int32))
             out["record_mode"] = {"pixels": int(args.record), "cap": 64, "segments": int(counts.sum()),
                                   "overflowed_pixels": int((counts > 64).sum()),
                                   "frame_plus_records_ms": (time.perf_counter() - t0) * 1e3}

@@ -14,13 +14,13 @@ for wl in $wls; do
   timeout -k 10 400 python3 bench.py --workload $wl --steps $steps --warmup $warm > $out/bench_$wl.json 2> $out/bench_$wl.err || { tail -5 $out/bench_$wl.err; exit 1; }
   if [ -f raytracing_amd/libvrt_cnt.so ]; then
     echo "== $wl nodes and primitives per ray (counting build)"
-    VRT_LIB=$GRAFT_REPO_ROOT/raytracing_amd/libvrt_cnt.so timeout -k 10 300 python3 bench.py --workload $wl --steps 1 --warmup 1 --min-time 0 --no-cpu-baseline --frames-8k 0 > $out/cnt_$wl.json 2> $out/cnt_$wl.err || { tail -5 $out/cnt_$wl.err; exit 1; }
+    VRT_LIB=$GRAFT_REPO_ROOT/raytracing_amd/libvrt_cnt.so timeout -k 10 300 python3 bench.py --workload $wl --steps 1 --warmup 1 --min-time 0 --no-cpu-baseline --no-host-path --frames-8k 0 > $out/cnt_$wl.json 2> $out/cnt_$wl.err || { tail -5 $out/cnt_$wl.err; exit 1; }
   fi
   echo "== $wl kernel trace"
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_$wl -- python3 bench.py --workload $wl --steps $steps --warmup $warm --min-time 0 --no-cpu-baseline --frames-8k 0 > $out/trace_$wl.log 2>&1 || { tail -5 $out/trace_$wl.log; exit 1; }
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_$wl -- python3 bench.py --workload $wl --steps $steps --warmup $warm --min-time 0 --no-cpu-baseline --no-host-path --frames-8k 0 > $out/trace_$wl.log 2>&1 || { tail -5 $out/trace_$wl.log; exit 1; }
   for c in FETCH_SIZE WRITE_SIZE; do
     echo "== $wl $c"
-    timeout -s KILL 120 rocprofv3 --pmc $c --output-format csv -d $out/pmc_${wl}_$c -- python3 bench.py --workload $wl --steps 3 --warmup 1 --min-time 0 --no-cpu-baseline --frames-8k 0 > $out/pmc_${wl}_$c.log 2>&1 || { tail -5 $out/pmc_${wl}_$c.log; exit 1; }
+    timeout -s KILL 120 rocprofv3 --pmc $c --output-format csv -d $out/pmc_${wl}_$c -- python3 bench.py --workload $wl --steps 3 --warmup 1 --min-time 0 --no-cpu-baseline --no-host-path --frames-8k 0 > $out/pmc_${wl}_$c.log 2>&1 || { tail -5 $out/pmc_${wl}_$c.log; exit 1; }
   done
   echo "== $wl SQ passes"
   tools/pmc.sh $tag/sq_$wl $wl > $out/sq_$wl.txt 2>&1 || { tail -5 $out/sq_$wl.txt; exit 1; }
