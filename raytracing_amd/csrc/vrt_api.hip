@@ -807,7 +807,7 @@ static int ensure_wf(vrt_ctx* c, size_t slots, bool two, hipStream_t stream)
 // (clock ticks per tile) come from a frame of the same layout on the same scene: that frame runs
 // in tile order and reports them, a radix sort behind it on the same stream turns them into the
 // order (descending, ties by tile number), and the frames after it use the order; every 16th
-// refreshes it.  The camera is not part of the layout on purpose: a host that moves it a little
+// refreshes it (every 256th on the brute-force scenes, whose frames are short).  The camera is not part of the layout on purpose: a host that moves it a little
 // every frame still dispatches by the costs of a frame ago.  Nothing about a frame's result
 // depends on the order.  Returns with P.tile_order / P.tile_cost set (or left null) and *sort_after
 // telling the caller to enqueue the sort behind the frame.
@@ -845,7 +845,9 @@ static int plan_tile_order(vrt_ctx* c, DevParams& P, hipStream_t stream, bool* s
     }
     const bool same = c->tile_valid && memcmp(sig, c->tile_sig, sizeof sig) == 0;
     if (same) P.tile_order = c->d_tile_order;
-    if (!same || (++c->tile_age & 15u) == 0) {
+    // the sort behind a recording frame is a third of a brute-force 1080p frame: those refresh rarely
+    const unsigned period_mask = c->sb.use_bvh ? 15u : 255u;
+    if (!same || (++c->tile_age & period_mask) == 0) {
         P.tile_cost = c->d_tile_cost;
         *sort_after = true;
         memcpy(c->tile_sig, sig, sizeof sig);
@@ -907,7 +909,8 @@ static int enqueue_frame(vrt_ctx* c, const vrt_params* p, const DevParams& P_in,
         } else {
             bool sort_after = false;
             size_t n_tiles = 0;
-            if (may_order && c->opt.tile_sort && c->sb.use_bvh && !P.xcd_remap) {
+            // tree scenes, and the brute-force scenes whose kernel has instantiations with the order
+            if (may_order && c->opt.tile_sort && !P.xcd_remap && (c->sb.use_bvh || (!two && vrt_scene_is_simple(S)))) {
                 int rc = plan_tile_order(c, P, stream, &sort_after, &n_tiles);
                 if (rc) return rc;
             }

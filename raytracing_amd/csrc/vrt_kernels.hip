@@ -34,7 +34,11 @@ namespace VRT_FORM {
 // SIMPLE (brute-force scenes only) is the instantiation for scenes of spheres and world-axis boxes
 // without triangles or textures, such as the shipped teaching scene: with those facts known at
 // compile time the unused loops and branches, and the registers they keep alive, disappear.
-template <bool BVH, bool TWOCHILD, bool SPLIT, bool SIMPLE>
+// ORD (brute-force instantiations for simple scenes only; the tree kernels decide at run time):
+// 0 tiles in block order, 1 tile looked up in P.tile_order, 2 as 1 when there is an order, and the
+// wave reports its cost.  Separate instantiations because the frame kernel of the teaching scene
+// loses 5 % to the two scalars the run-time form keeps alive.
+template <bool BVH, bool TWOCHILD, bool SPLIT, bool SIMPLE, int ORD = 0>
 __global__ __launch_bounds__(VRT_MEGA_THREADS, BVH ? VRT_BVH_WAVES : (SIMPLE ? VRT_SIMPLE_WAVES : 4)) void k_mega(DevScene S_in, DevCam cam, DevParams P, float4* __restrict__ rgba,
                                               int* __restrict__ hit_id, unsigned long long* ctr,
                                               int blocks_x, int n_blocks)
@@ -56,9 +60,12 @@ __global__ __launch_bounds__(VRT_MEGA_THREADS, BVH ? VRT_BVH_WAVES : (SIMPLE ? V
     // 2 % from the order and loses 5 % to the two more live scalars.)
     long long t_start = 0ll;
     unsigned tile = bid;
-    if constexpr (BVH) {
+    if constexpr (BVH || ORD == 2) {
         if (P.tile_cost) t_start = clock64();
         if (P.tile_order) bid = (unsigned)P.tile_order[bid];
+        tile = bid;
+    } else if constexpr (ORD == 1) {
+        bid = (unsigned)P.tile_order[bid];
         tile = bid;
     }
     const int bx = bid % blocks_x, by = bid / blocks_x;
@@ -142,7 +149,7 @@ __global__ __launch_bounds__(VRT_MEGA_THREADS, BVH ? VRT_BVH_WAVES : (SIMPLE ? V
         if (hit_id) hit_id[idx] = id;
     }
     flush_counters(C, ctr, blockIdx.x);
-    if constexpr (BVH) {
+    if constexpr (BVH || ORD == 2) {
         if (P.tile_cost && threadIdx.x == 0) P.tile_cost[tile] = (unsigned)(clock64() - t_start);
     }
 }
@@ -238,18 +245,25 @@ hipError_t vrt_launch_mega(const DevScene& S, const DevCam& cam, const DevParams
     if (n_blocks <= 0) return hipSuccess;
     dim3 grid(n_blocks), block(VRT_MEGA_THREADS);
 #if !VRT_SLAB_FMA
-    const bool simple = !bvh && S.n_tri == 0 && S.all_aab && !S.mat_tex && !S.has_matte && !S.has_transparent;
+    const bool simple = !bvh && vrt_scene_is_simple(S);
+    const int ord = P.tile_cost ? 2 : (P.tile_order ? 1 : 0);
 #endif
 #define VRT_GO3(B, T, SP, SI) hipLaunchKernelGGL((k_mega<B, T, SP, SI>), grid, block, 0, stream, S, cam, P, rgba, hit_id, ctr, blocks_x, n_blocks)
 #define VRT_GO(B, T) do { if (shift == 0) VRT_GO3(B, T, false, false); else VRT_GO3(B, T, true, false); } while (0)
 #define VRT_GOS(T) do { if (shift == 0) VRT_GO3(false, T, false, true); else VRT_GO3(false, T, true, true); } while (0)
+#define VRT_GO5(SP, O) hipLaunchKernelGGL((k_mega<false, false, SP, true, O>), grid, block, 0, stream, S, cam, P, rgba, hit_id, ctr, blocks_x, n_blocks)
+#define VRT_GOSO(O) do { if (shift == 0) VRT_GO5(false, O); else VRT_GO5(true, O); } while (0)
     if (bvh) { if (twochild) VRT_GO(true, true); else VRT_GO(true, false); }
 #if VRT_SLAB_FMA
     else return hipErrorInvalidValue;   // the fused form only differs where a tree is walked
 #else
+    else if (simple && !twochild && ord == 1) VRT_GOSO(1);
+    else if (simple && !twochild && ord == 2) VRT_GOSO(2);
     else if (simple) { if (twochild) VRT_GOS(true); else VRT_GOS(false); }
     else     { if (twochild) VRT_GO(false, true); else VRT_GO(false, false); }
 #endif
+#undef VRT_GOSO
+#undef VRT_GO5
 #undef VRT_GOS
 #undef VRT_GO3
 #undef VRT_GO

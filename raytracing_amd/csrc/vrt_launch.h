@@ -59,6 +59,13 @@ struct WfWorkspace {
                                     bool twochild, const WfWorkspace& W, float4* rgba, int* hit_id, \
                                     unsigned long long* ctr, hipStream_t stream); \
 
+// Scenes of spheres and world-axis boxes without textures or the general materials take the
+// megakernel's instantiation for them (k_mega<..., SIMPLE>).
+static inline bool vrt_scene_is_simple(const DevScene& S)
+{
+    return S.n_tri == 0 && S.all_aab && !S.mat_tex && !S.has_matte && !S.has_transparent;
+}
+
 namespace vrt_plain { VRT_LAUNCHERS }
 namespace vrt_fused { VRT_LAUNCHERS }
 #undef VRT_LAUNCHERS

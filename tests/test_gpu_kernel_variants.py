@@ -371,3 +371,33 @@ def test_frames_do_not_depend_on_the_tile_order(vrt_ctx):
         assert np.array_equal(a[0], b[0], equal_nan=True), step
         assert np.array_equal(a[1], b[1]) and a[2] == b[2], step
     assert ref[0][2] != ref[35][2]   # the scenes do differ
+
+
+def test_teaching_scene_frames_do_not_depend_on_the_tile_order(vrt_ctx):
+    """The brute-force kernel of simple scenes has instantiations of its own for the cost order
+    (order lookup; lookup + cost report): 260 consecutive frames, which crosses the first
+    recording frame, the ordered frames and the refresh after 256, must all equal the frame in tile
+    order; hit ids and ray counts too."""
+    import torch
+    scene, cam = ra.teaching_scene(), ra.teaching_camera(1040, 520)
+    prm = ra.Params(spp=1, max_depth=5)
+    vrt_ctx.set_scene(scene)
+    vrt_ctx.set_camera(cam)
+    dev = torch.empty((520, 1040, 4), dtype=torch.float32, device="cuda")
+    hit = torch.empty((520, 1040), dtype=torch.int32, device="cuda")
+    s = torch.cuda.current_stream()
+    try:
+        vrt_ctx.set_option("tile_sort", 0)
+        vrt_ctx.render_device(prm, dev.data_ptr(), hit.data_ptr(), s.cuda_stream)
+        torch.cuda.synchronize()
+        ref, ref_hit, ref_rays = torch.nan_to_num(dev.clone()), hit.clone(), list(vrt_ctx.fetch_stats().rays)
+        vrt_ctx.set_option("tile_sort", 1)
+        for step in range(260):
+            dev.fill_(-1.0); hit.fill_(-9)
+            vrt_ctx.render_device(prm, dev.data_ptr(), hit.data_ptr(), s.cuda_stream)
+            torch.cuda.synchronize()
+            assert torch.equal(torch.nan_to_num(dev), ref) and torch.equal(hit, ref_hit), step
+            if step in (0, 1, 2, 255, 256, 257):
+                assert list(vrt_ctx.fetch_stats().rays) == ref_rays, step
+    finally:
+        vrt_ctx.set_option("tile_sort", 1)
