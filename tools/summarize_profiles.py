@@ -20,11 +20,16 @@ traffic_path = os.path.join(dst, "traffic.json")
 traffic = json.load(open(traffic_path)) if os.path.exists(traffic_path) else {}
 
 
-def dominant(names):
-    for n in names:
+def dominant(acc):
+    """The frame kernel with the most dispatches (a frame that measures tile costs runs another
+    instantiation of k_mega once in a while)."""
+    best, best_n = None, -1
+    for n, counters in acc.items():
         if "k_mega" in n:
-            return n
-    return None
+            d = max(len(v) for v in counters.values())
+            if d > best_n:
+                best, best_n = n, d
+    return best
 
 
 for bench in sorted(glob.glob(os.path.join(src, "bench_*.json"))):
@@ -43,7 +48,7 @@ for bench in sorted(glob.glob(os.path.join(src, "bench_*.json"))):
             glob.glob(os.path.join(src, f"sq_{wl}", "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             acc[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    kern = dominant(acc.keys())
+    kern = dominant(acc)
     if kern:
         with open(os.path.join(dst, f"{prefix}_{wl}_pmc.csv"), "w", newline="") as f:
             w = csv.writer(f)
