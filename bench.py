@@ -271,6 +271,9 @@ def scaling_8k(local_rank, world, rank, dev, cdev, rehearsal, frames, tile_rows,
                      compact_rows=True, **dict(kw, spp=1))
     ctx.render_device(wprm, local.data_ptr(), None, stream.cuda_stream)
     fg.gather()
+    # one untimed frame at full cost: the first frame of a layout measures the tile costs the later
+    # ones are dispatched by, and the timed frames should be the steady state of a viewer
+    frame()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
