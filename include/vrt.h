@@ -271,7 +271,7 @@ int vrt_create_multi(int n_gpus, const int* devices, vrt_ctx** out);
 
 /* Study and test knobs by name ("sample_shift", "packet", "beam", "slab_fma", "quad_max", "stack_cap",
  * "wf_defer", "wf_refill", "wf_max_slots", "wf_any_cap", "wf_queue_cap", "builder", "collapse_parity",
- * "no_big", "xcd_remap", "block_compact", "zero_copy", "staged", "fail_after_build"); none changes a result.
+ * "no_big", "xcd_remap", "block_compact", "zero_copy", "staged", "tile_sort", "fail_after_build"); none changes a result.
  * builder / collapse_parity / no_big take effect at the next vrt_set_scene.  No counterpart in
  * the reference. */
 int vrt_set_option(vrt_ctx* ctx, const char* name, long long value);
