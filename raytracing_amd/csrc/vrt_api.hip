@@ -801,16 +801,18 @@ static int ensure_wf(vrt_ctx* c, size_t slots, bool two, hipStream_t stream)
 
 // Enqueues one frame on `stream`.  `ctr` = the counter block to count into (already clear), or
 // null for the path's own block, cleared here.
-// Tree scenes: the megakernel's tiles are dispatched most expensive first.  A launch keeps 79-93 %
+// Tree scenes (and the simple brute-force scenes): the megakernel's tiles are dispatched most
+// expensive first.  A launch keeps 79-93 %
 // of the chip's wave slots filled on the tree workloads; the rest is the tail, in which the last
 // tiles dispatched run alone, and its length is the duration of whatever those tiles are.  Costs
 // (clock ticks per tile) come from a frame of the same layout on the same scene: that frame runs
 // in tile order and reports them, a radix sort behind it on the same stream turns them into the
 // order (descending, ties by tile number), and the frames after it use the order; every 16th
-// refreshes it (every 256th on the brute-force scenes, whose frames are short).  The camera is not part of the layout on purpose: a host that moves it a little
-// every frame still dispatches by the costs of a frame ago.  Nothing about a frame's result
-// depends on the order.  Returns with P.tile_order / P.tile_cost set (or left null) and *sort_after
-// telling the caller to enqueue the sort behind the frame.
+// refreshes it (every 256th on the brute-force scenes, whose frames are short).  The camera is not
+// part of the layout on purpose: a host that moves it a little every frame still dispatches by the
+// costs of a frame ago.  Nothing about a frame's result depends on the order.  Returns with
+// P.tile_order / P.tile_cost set (or left null) and *sort_after telling the caller to enqueue the
+// sort behind the frame.
 static int plan_tile_order(vrt_ctx* c, DevParams& P, hipStream_t stream, bool* sort_after, size_t* n_tiles)
 {
     *sort_after = false;
