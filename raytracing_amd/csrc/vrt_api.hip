@@ -162,6 +162,7 @@ static void teardown(vrt_ctx* c)
     if (c->static_stage) hipHostFree(c->static_stage);
     for (auto& r : c->registered) { void* base; size_t len; page_range(r.first, r.second, &base, &len); hipHostUnregister(base); }
     c->registered.clear();
+    delete c->copy_helper; c->copy_helper = nullptr;
     for (void* p : c->host_allocs) hipHostFree(p);
     c->host_allocs.clear();
     c->host_alloc_bytes.clear();
@@ -1152,10 +1153,11 @@ static int render_staged(vrt_ctx* c, const vrt_params* p, float* rgba_out, int32
         }
     };
     {
-        std::vector<std::thread> helpers;
-        for (int t = 1; t < n_thr; ++t) helpers.emplace_back(copy_bands, t);
+        static_assert(VRT_STAGED_THREADS == 2, "one helper thread per context");
+        if (!c->copy_helper) c->copy_helper = new HostHelper();
+        c->copy_helper->post([&] { copy_bands(1); });
         copy_bands(0);
-        for (auto& h : helpers) h.join();
+        c->copy_helper->wait();
     }
     for (int k = 0; k < VRT_STAGED_THREADS; ++k)
         if (err[k] != hipSuccess) {

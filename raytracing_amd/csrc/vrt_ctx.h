@@ -2,7 +2,11 @@
 // vrt_multi.hip (several GPUs of one node behind the same entry points).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -63,6 +67,49 @@ struct OffsetSlot {
 
 struct VrtMulti;   // vrt_multi.hip
 
+// A host thread that runs one job at a time for its context (the second copier of frames staged
+// for pageable memory): started on first use, joined when the context goes.
+class HostHelper {
+public:
+    HostHelper() : th_([this] { loop(); }) {}
+    ~HostHelper()
+    {
+        { std::lock_guard<std::mutex> g(m_); quit_ = true; }
+        cv_.notify_all();
+        th_.join();
+    }
+    void post(std::function<void()> job)
+    {
+        { std::lock_guard<std::mutex> g(m_); job_ = std::move(job); busy_ = true; }
+        cv_.notify_all();
+    }
+    void wait()
+    {
+        std::unique_lock<std::mutex> g(m_);
+        done_.wait(g, [this] { return !busy_; });
+    }
+private:
+    void loop()
+    {
+        std::unique_lock<std::mutex> g(m_);
+        for (;;) {
+            cv_.wait(g, [this] { return quit_ || busy_; });
+            if (quit_) return;
+            std::function<void()> job = std::move(job_);
+            g.unlock();
+            job();
+            g.lock();
+            busy_ = false;
+            done_.notify_all();
+        }
+    }
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    std::function<void()> job_;
+    bool busy_ = false, quit_ = false;
+    std::thread th_;   // last: started when everything above exists
+};
+
 struct vrt_ctx {
     int device = 0;
     std::string err;
@@ -105,6 +152,7 @@ struct vrt_ctx {
     unsigned long long scene_gen = 0;          // bumped by every scene swap
     // page-locked staging of vrt_render for callers whose frame buffer the device cannot reach (pageable memory)
     float* stage_rgba = nullptr; int32_t* stage_hit = nullptr; size_t stage_px = 0;
+    HostHelper* copy_helper = nullptr;
     // wavefront workspace
     WfWorkspace wf; bool wf_two = false; bool wf_short = false;
     // the device's copy of the library's static scratch array (vrt_render_device_noalloc) and the
