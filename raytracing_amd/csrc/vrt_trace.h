@@ -816,6 +816,10 @@ __device__ __noinline__ int beam_collect(const float4* bvh4, int n_prims, float 
                                          float o_y, float o_z, float lim, int live_i, int one_origin,
                                          unsigned long long* dbg)
 {
+    // The wave-wide reductions below read lane 63 and DPP sources in every row: with a lane of the
+    // wave switched off they would return stale registers, so a partial wave does not take the beam
+    // (the caller traverses per lane instead).
+    if (__builtin_amdgcn_read_exec() != ~0ull) return -1;
     const bool live = live_i != 0;
     const unsigned long long lm = __ballot(live);
     if (lm == 0ull) return 0;
@@ -873,7 +877,7 @@ __device__ __noinline__ int beam_collect(const float4* bvh4, int n_prims, float 
                 atomicAdd(&dbg[(blockIdx.x % VRT_CTR_SLOTS) * VRT_CTR_STRIDE + 6], (unsigned long long)__popcll(m));
         }
 #endif
-        if (node >= 0) {
+        if ((unsigned)node < (unsigned)(n_prims - 1)) {   // a tree over n primitives has n - 1 inner nodes
             const VRT_CONST_AS float* nb = (const VRT_CONST_AS float*)(bvh4 + 8 * (size_t)node) + c;
             const float lox = nb[0], loy = nb[4], loz = nb[8], hix = nb[12], hiy = nb[16], hiz = nb[20];
             code = __float_as_int(nb[24]);
@@ -886,12 +890,16 @@ __device__ __noinline__ int beam_collect(const float4* bvh4, int n_prims, float 
                 const float sn = POS ? LO - OH : HI - OL, sf = POS ? HI - OL : LO - OH;     \
                 tn = fmaxf(tn, fminf(sn * IL, sn * IH));                                    \
                 tf = fminf(tf, fmaxf(sf * IL, sf * IH));                                    \
-            } else if (!(LO <= HI)) tf = -INFINITY;   /* an unused child slot */
+            }
             VRT_BEAM_AXIS(cx, px, lox, hix, olx, ohx, ilx, ihx)
             VRT_BEAM_AXIS(cy, py, loy, hiy, oly, ohy, ily, ihy)
             VRT_BEAM_AXIS(cz, pz, loz, hiz, olz, ohz, ilz, ihz)
 #undef VRT_BEAM_AXIS
-            hit = tn <= tf * 1.00001f + 1e-6f;
+            // An unused child slot holds a box at +inf, which every constrained axis rejects (its
+            // entry distance is +inf or its exit distance -inf).  When the live rays' directions
+            // differ in sign, or are not finite, on all three axes nothing constrains, and the
+            // slot has to be told by its code: as a "leaf" it would name primitive 0x7fffffff.
+            hit = tn <= tf * 1.00001f + 1e-6f && code != VRT_BVH4_EMPTY;
         }
         const bool inner = hit && code >= 0, leaf = hit && code < 0;
         const unsigned long long mi = __ballot(inner), ml = __ballot(leaf);
@@ -912,6 +920,7 @@ __device__ __forceinline__ bool intersect_bvh4_beam(const DevScene& S, Trav& T, 
     if (n_cand < 0) return false;
     for (int k = 0; k < n_cand; ++k) {
         const int id = __builtin_amdgcn_readfirstlane(*beam_slot(VRT_BEAM_FRONT + k));
+        if ((unsigned)id >= (unsigned)S.n_prims) continue;   // cannot happen; a wild id must not become an address
         count_lanes(S, 7, live);
         if (live && id != T.skip) test_prim(S, id, T.o, T.d, T.maxd, T.best);
     }
@@ -958,6 +967,7 @@ __device__ __forceinline__ bool occluded_wave(const DevScene& S, bool want, f3 o
     for (int k = 0; k < n_cand; ++k) {
         if (!__any(need && !found)) break;
         const int id = __builtin_amdgcn_readfirstlane(*beam_slot(VRT_BEAM_FRONT + k));
+        if ((unsigned)id >= (unsigned)S.n_prims) continue;   // as in intersect_bvh4_beam
         count_lanes(S, 7, need && !found);
         if (need && !found && id != skip) {
             test_prim(S, id, T.o, T.d, T.maxd, T.best);

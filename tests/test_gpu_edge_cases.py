@@ -155,3 +155,45 @@ def test_large_nodes_of_the_device_build(vrt_ctx, oracle_mod):
         finally:
             vrt_ctx.set_option("builder", -1)
         assert np.array_equal(got, ref, equal_nan=True) and np.array_equal(got_hit, ref_hit)
+
+
+def _amid_scene(n_spheres, seed):
+    """A small tree scene (49-90 primitives) whose occlusion rays leave a wave in every direction:
+    a box whose top and +x faces are seen together (ambient-occlusion rays along (0,1,0) and
+    (1,0,0): two infinite reciprocals each), and point lights that sit amid the spheres, just above
+    the ground, so that the shadow rays of one 8x8-pixel wave differ in sign on all three axes."""
+    s = ra.Scene()
+    met = s.add_material("Metal", abi.VRT_MAT_METAL, (0.9, 0.85, 0.8))
+    red = s.add_material("Red", abi.VRT_MAT_SOLID, (1.0, 0.25, 0.2))
+    gls = s.add_material("Dielectric", abi.VRT_MAT_DIELECTRIC, (1, 1, 1))
+    rng = np.random.default_rng(seed)
+    for k in range(n_spheres):
+        c = (rng.uniform(-2.2, 2.2), rng.uniform(0.25, 1.6), rng.uniform(-1.0, 3.0))
+        s.add_sphere(c, rng.uniform(0.12, 0.3), (met, red, gls)[k % 3])
+    s.add_box((-1.2, 0.3, -0.8), (0.5, 0.3, 0.5), red)      # top and +x faces towards the camera
+    s.add_box((1.4, 0.2, 0.2), (0.4, 0.2, 0.6), met)
+    s.add_box((0, -0.5, 1.0), (7, 0.5, 7), red)             # ground: kept out of the tree
+    s.add_light(abi.VRT_LIGHT_POINT, (0.1, 0.12, 0.6), ls=0.7, cast_shadows=True)   # amid the spheres
+    s.add_light(abi.VRT_LIGHT_POINT, (-0.9, 0.9, 0.1), ls=0.5, cast_shadows=True)   # beside the box
+    s.add_light(abi.VRT_LIGHT_DIRECTIONAL, (0.3, 0.8, -0.5), ls=0.4, cast_shadows=False)
+    return s
+
+
+@pytest.mark.parametrize("n_spheres", [46, 87])
+def test_small_tree_with_rays_in_every_direction(vrt_ctx, vrt_opts, oracle_mod, n_spheres):
+    """Waves whose occlusion rays constrain no axis of the shared candidate collection (directions of
+    both signs, or parallel to an axis, on x, y and z at once): then only its code tells an unused
+    child slot of a 4-wide node from a leaf.  49 and 90 primitives: the whole tree fits the
+    candidate list, so nothing falls back to the per-lane traversal."""
+    s = _amid_scene(n_spheres, seed=5)
+    assert s.n_prims == n_spheres + 3
+    cam = ra.make_camera((0.3, 2.6, -5.5), (-2.2, 0.4, -2.5), (4.4, 0, 0), (0, 3.0, -0.9), 96, 72)
+    offs = host.sampler_table(abi.VRT_SAMPLER_JITTERED, 4, 5, 0.04, 0.04, seed=3)
+    for flags in (0, abi.VRT_FIX_AO_BASIS, abi.VRT_FIX_AO_BASIS | abi.VRT_FIX_DIELECTRIC):
+        for slab_fma in (1, 0):
+            vrt_opts("slab_fma", slab_fma)
+            rgba, hit, st = _cmp(vrt_ctx, oracle_mod, s, cam, ra.Params(spp=1, max_depth=4, flags=flags))
+            assert st.bvh_nodes == s.n_prims - 1 and st.rays[abi.VRT_RAY_SHADOW] > 0 and st.rays[abi.VRT_RAY_AO] > 0
+            _cmp(vrt_ctx, oracle_mod, s, cam, ra.Params(spp=4, offsets=offs, seed=1, max_depth=4, flags=flags))
+    vrt_opts("sample_shift", 0)   # 8x8-pixel waves with four samples looped per lane
+    _cmp(vrt_ctx, oracle_mod, s, cam, ra.Params(spp=4, offsets=offs, seed=1, max_depth=4, flags=abi.VRT_FIX_AO_BASIS))

@@ -1,0 +1,107 @@
+// How many wave64 vector instructions can one SIMD of gfx950 issue per clock?
+//
+// Every wave runs N_CHAIN independent v_fma_f32 dependency chains (so latency does not bound a
+// wave's own stream); blocks are four waves (one per SIMD) and k blocks are kept resident per CU by
+// giving each 160 KiB / k of LDS, i.e. k waves per SIMD.  The program prints, per k, the wave
+// instructions issued per SIMD and nominal clock (chip-wide time x 2.4 GHz), with plain v_fma_f32,
+// with v_pk_fma_f32 and with a 50:50 mix of v_fma_f32 and v_xor_b32 (an integer filler).
+//
+// build: hipcc -O2 --offload-arch=gfx950 tools/exp/valu_issue.hip -o tools/exp/valu_issue
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+constexpr int N_CHAIN = 8;
+constexpr int UNROLL = 16;           // fma per chain per loop turn
+extern __shared__ char g_dyn[];
+
+template <int KIND>
+__global__ __launch_bounds__(256) void k_issue(float* out, int iters, float a, float b)
+{
+    float v[N_CHAIN];
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    v2f p[N_CHAIN / 2];
+#pragma unroll
+    for (int c = 0; c < N_CHAIN; ++c) v[c] = (float)(threadIdx.x + c);
+#pragma unroll
+    for (int c = 0; c < N_CHAIN / 2; ++c) p[c] = v2f{(float)threadIdx.x, (float)c};
+    int fill[N_CHAIN / 2];
+#pragma unroll
+    for (int c = 0; c < N_CHAIN / 2; ++c) fill[c] = threadIdx.x + c;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            if (KIND == 0) {
+#pragma unroll
+                for (int c = 0; c < N_CHAIN; ++c) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[c]) : "v"(a), "v"(b));
+            } else if (KIND == 1) {
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int c = 0; c < N_CHAIN / 2; ++c)
+                        asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[c]) : "v"(v2f{a, a}), "v"(v2f{b, b}));
+            } else {
+#pragma unroll
+                for (int c = 0; c < N_CHAIN / 2; ++c) {
+                    asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[c]) : "v"(a), "v"(b));
+                    asm volatile("v_xor_b32 %0, %0, %1" : "+v"(fill[c]) : "v"(it));
+                }
+            }
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < N_CHAIN; ++c) s += v[c];
+#pragma unroll
+    for (int c = 0; c < N_CHAIN / 2; ++c) s += p[c].x + p[c].y;
+    int filler = 0;
+#pragma unroll
+    for (int c = 0; c < N_CHAIN / 2; ++c) filler ^= fill[c];
+    if (s == 12345.678f || filler == -77) out[0] = s + g_dyn[0];   // keeps the chains alive, never true
+}
+
+template <int KIND>
+static void run(const char* name, int n_cu, float* d_out, double clock_hz)
+{
+    const int iters = 4096;
+    for (int k : {1, 2, 4, 8}) {
+        const int lds = (160 * 1024) / k - 256;   // k blocks of 4 waves per CU
+        CK(hipFuncSetAttribute((const void*)k_issue<KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        const int blocks = n_cu * k;
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        hipLaunchKernelGGL(k_issue<KIND>, dim3(blocks), dim3(256), lds, 0, d_out, 64, 1.0001f, 0.5f);   // warm-up
+        CK(hipDeviceSynchronize());
+        float best = 1e30f;
+        for (int rep = 0; rep < 5; ++rep) {
+            CK(hipEventRecord(e0));
+            hipLaunchKernelGGL(k_issue<KIND>, dim3(blocks), dim3(256), lds, 0, d_out, iters, 1.0001f, 0.5f);
+            CK(hipEventRecord(e1));
+            CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            if (ms < best) best = ms;
+        }
+        const double insts_per_wave = (double)iters * UNROLL * N_CHAIN;   // every kind issues N_CHAIN per unroll step
+        const double waves_per_simd = k;
+        const double cycles = best * 1e-3 * clock_hz;
+        printf("%-28s waves/SIMD %d  %.3f ms  wave-instr per SIMD-cycle %.3f  (cycles per wave-instr %.2f)\n", name, k, best,
+               insts_per_wave * waves_per_simd / cycles, cycles / (insts_per_wave * waves_per_simd));
+    }
+}
+
+int main()
+{
+    hipDeviceProp_t prop;
+    CK(hipGetDeviceProperties(&prop, 0));
+    const double clock_hz = prop.clockRate * 1e3;
+    printf("%s: %d CUs, clockRate %.0f MHz\n", prop.gcnArchName, prop.multiProcessorCount, clock_hz / 1e6);
+    float* d_out;
+    CK(hipMalloc(&d_out, 256));
+    run<0>("v_fma_f32", prop.multiProcessorCount, d_out, clock_hz);
+    run<1>("v_pk_fma_f32", prop.multiProcessorCount, d_out, clock_hz);
+    run<2>("v_fma_f32 + v_xor_b32 1:1", prop.multiProcessorCount, d_out, clock_hz);
+    CK(hipFree(d_out));
+    return 0;
+}
