@@ -768,6 +768,12 @@ __device__ __forceinline__ bool intersect_bvh4_packet(const DevScene& S, Trav& T
 #ifndef VRT_BEAM_FRONT
 #define VRT_BEAM_FRONT 160
 #endif
+// VRT_BEAM_BOUNCE=1: the first reflections of the hits of a wave's camera rays are cast together too
+// (intersect_bounce_wave).  A compile-time choice: as a run-time switch, with both paths in the
+// kernel, it cost the tree kernels 3-8 % in register allocation.
+#ifndef VRT_BEAM_BOUNCE
+#define VRT_BEAM_BOUNCE 1
+#endif
 #ifndef VRT_BEAM_CAND
 #define VRT_BEAM_CAND 96
 #endif
@@ -978,6 +984,34 @@ __device__ __forceinline__ bool occluded_wave(const DevScene& S, bool want, f3 o
         }
     }
     return found;
+}
+
+// Closest hits of rays a wave casts together from different points (the first reflections of the
+// hits of its camera rays: neighbouring pixels or samples of one pixel mirror in neighbouring
+// surface points).  Every lane of the wave calls, want = this lane has a ray (direction not zero).
+// The candidates are collected once for the wave, with the origins as an interval, and ranked per
+// lane by (t, id), so a lane's hit is the one its own traversal finds; a beam too wide for the
+// lists leaves every lane to that traversal.
+__device__ __forceinline__ Hit intersect_bounce_wave(const DevScene& S, bool want, f3 o, f3 d, float maxd, int skip,
+                                                     bool packet)
+{
+    Trav T;
+    trav_begin(T, o, d, maxd, INFINITY, skip);
+    if (want) trav_big(S, T, false);
+    const int n_cand = __builtin_amdgcn_readfirstlane(
+        beam_collect(S.bvh4, S.n_prims, T.inv.x, T.inv.y, T.inv.z, o.x, o.y, o.z, trav_limit(T), want ? 1 : 0, 0, S.dbg));
+    if (n_cand < 0) {
+        Hit h; h.prim = -1; h.t = INFINITY; h.aux = 0;
+        if (want) h = intersect_bvh4(S, o, d, maxd, INFINITY, skip, false, packet);
+        return h;
+    }
+    for (int k = 0; k < n_cand; ++k) {
+        const int id = __builtin_amdgcn_readfirstlane(*beam_slot(VRT_BEAM_FRONT + k));
+        if ((unsigned)id >= (unsigned)S.n_prims) continue;   // as in intersect_bvh4_beam
+        count_lanes(S, 7, want);
+        if (want && id != skip) test_prim(S, id, T.o, T.d, T.maxd, T.best);
+    }
+    return T.best;
 }
 
 // ------------------------------------------------------------------ four lanes per ray
@@ -1618,11 +1652,14 @@ struct PendingRay { f3 o, d, T; int depth, skip, kind; };
 // refracting hit waits on a bounded per-lane stack.
 template <bool BVH, bool RECORD, bool TWOCHILD>
 // shaded: the first hit has been shaded already (its Bounce), the loop starts at its children.
+// L0, T0: radiance gathered and throughput reached before (o, d) was cast (a path taken up after its
+// first bounce); the sums go on in the order of the path traced from the camera, so the bits agree.
 __device__ __forceinline__ f3 trace_path(const DevScene& S, const DevParams& P, f3 o, f3 d, Hit first,
-                                         Counters& C, Recorder& R, int depth0 = 0, const Bounce* shaded = nullptr)
+                                         Counters& C, Recorder& R, int depth0 = 0, const Bounce* shaded = nullptr,
+                                         f3 L0 = {0.f, 0.f, 0.f}, f3 T0 = {1.f, 1.f, 1.f})
 {
-    f3 L = mk3(0.f, 0.f, 0.f);
-    f3 T = mk3(1.f, 1.f, 1.f);
+    f3 L = L0;
+    f3 T = T0;
     int depth = depth0, skip = -1, kind = VRT_RAY_PRIMARY;
     Hit h = first;
     bool have_first = true;
@@ -1713,6 +1750,29 @@ __device__ __forceinline__ f3 trace_sample_dev(const DevScene& S, const DevCam& 
             unsigned bits = cap.bits;
             if (occluded_wave(S, hit && (cap.has & 1u), point, cap.d0, cap.maxd0, cap.tlim0, first.prim, P.packet != 0)) bits |= 1u;
             if (occluded_wave(S, hit && (cap.has & 2u), point, cap.d1, cap.maxd1, cap.tlim1, first.prim, P.packet != 0)) bits |= 2u;
+            if constexpr (VRT_BEAM_BOUNCE && !TWOCHILD) {
+                // The first reflections of the wave's hits are cast together as well (neighbouring
+                // surface points mirror into neighbouring directions), and each lane takes its path
+                // up from there.
+                Bounce B;
+                B.n_child = 0; B.o = O; B.d0 = d; B.prim = -1;
+                if (hit) {
+                    OccBits answers; answers.bits = bits;
+                    shade_hit<BVH, false>(S, P, first, O, d, 0, C, R, B, answers);
+                }
+                const bool go = hit && B.n_child > 0 && 1 <= P.max_depth;
+                const bool cast1 = go && !is_zero3(B.d0);
+                if (cast1) VRT_COUNT(C, reflect, VRT_RAY_REFLECT);
+                const Hit h1 = intersect_bounce_wave(S, cast1, B.o, B.d0, P.range, B.prim, P.packet == 2);
+                if (hit) {
+                    const f3 L0 = mk3(0.f, 0.f, 0.f) + mk3(1.f, 1.f, 1.f) * B.A;
+                    if (!go) return L0;
+                    return trace_path<BVH, false, TWOCHILD>(S, P, B.o, B.d0, h1, C, R, 1, nullptr, L0, mk3(1.f, 1.f, 1.f) * B.w0);
+                }
+                if (!live) return mk3(0.f, 0.f, 0.f);
+                if (P.flags & VRT_FIX_PRIMARY_SKY) return sky_color(d);
+                return mk3(0.f, 0.f, 0.f);
+            }
             if (!live) return mk3(0.f, 0.f, 0.f);
             if (hit) {
                 OccBits answers; answers.bits = bits;
