@@ -201,10 +201,11 @@ def cpu_baseline(scene, cam, prm):
 
 
 def in_library_multi(n_gpus, workload, steps):
-    """The same split behind the C ABI (vrt_create_multi: one host thread per GPU, strips gathered to
-    the first GPU with RCCL, assembled and tone-mapped there, frame copied to page-locked host
-    memory), measured in a child process of its own after the ranks of this job have gone idle:
-    the call a one-process host such as Unity makes.  Returns a dict or a short reason."""
+    """The same split behind the C ABI (vrt_create_multi: one host thread per GPU; every GPU stores
+    the rows of its strips into the caller's page-locked frame buffer itself, over its own PCIe
+    link), measured in a child process of its own after the ranks of this job have gone idle: the
+    call a one-process host such as Unity makes.  Also timed with the strips gathered on the first
+    GPU over xGMI and read back from there (option multi_gather).  Returns a dict or a short reason."""
     import subprocess
     code = r"""
 import json, sys, time
@@ -223,15 +224,25 @@ one.close()
 m = host.Context(devices=list(range(n)))
 m.set_scene(scene); m.set_camera(cam)
 rgba, hit = m.host_alloc(want.shape, np.float32), m.host_alloc(want_hit.shape, np.int32)
-m.render(prm, rgba=rgba, hit=hit)
-ts = []
-for _ in range(steps):
-    t0 = time.perf_counter(); _, _, st = m.render(prm, rgba=rgba, hit=hit); ts.append((time.perf_counter() - t0) * 1e3)
-q = float(sum(st.rays[1:]))
-print(json.dumps({"workload": label, "gpus": n, "ms_per_frame_host": float(np.median(ts)), "gpu_ms": st.gpu_ms,
-                  "Mrays_per_s": q / float(np.median(ts)) / 1e3,
-                  "frame_equals_one_gpu": bool(np.array_equal(rgba, want, equal_nan=True) and np.array_equal(hit, want_hit)),
-                  "rays_equal_one_gpu": list(st.rays) == list(st1.rays)}))
+res = {"workload": label, "gpus": n}
+for gather in (0, 1):
+    m.set_option("multi_gather", gather)
+    rgba[:] = 0; hit[:] = -9
+    m.render(prm, rgba=rgba, hit=hit)
+    m.render(prm, rgba=rgba, hit=hit)
+    ts = []
+    for _ in range(steps):
+        t0 = time.perf_counter(); _, _, st = m.render(prm, rgba=rgba, hit=hit); ts.append((time.perf_counter() - t0) * 1e3)
+    q = float(sum(st.rays[1:]))
+    r = {"ms_per_frame_host": float(np.median(ts)), "gpu_ms": st.gpu_ms, "Mrays_per_s": q / float(np.median(ts)) / 1e3,
+         "frame_equals_one_gpu": bool(np.array_equal(rgba, want, equal_nan=True) and np.array_equal(hit, want_hit)),
+         "rays_equal_one_gpu": list(st.rays) == list(st1.rays)}
+    if gather == 0:
+        res.update(r)
+        res["delivery"] = "every GPU stores its strips into the page-locked frame buffer over its own PCIe link"
+    else:
+        res["gathered_on_first_gpu"] = r
+print(json.dumps(res))
 """ % (ROOT, n_gpus, workload, steps)
     try:
         out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=240)

@@ -262,16 +262,22 @@ const char* vrt_last_error(vrt_ctx* ctx);
 
 /* The same context over n_gpus GPUs of one node (devices = their HIP ordinals, NULL = 0..n_gpus-1).
  * The Unity host is one process with one main thread (RayTracerUnity.cs:312-352), so the split
- * lives behind the boundary: vrt_set_scene / vrt_set_camera replicate to every GPU, vrt_render
- * deals 8-row strips of the frame round-robin to the GPUs (one host thread and stream each, all
- * samples of a strip on its GPU), gathers the strips to the first GPU with RCCL send/recv over
- * xGMI, tone-maps there and copies the frame to the caller.  vrt_trace_pixel / vrt_trace_ray run
- * on the first GPU.  The non-blocking and device-pointer calls are not offered on such a context. */
+ * lives behind the boundary: vrt_set_scene / vrt_set_camera replicate to every GPU, vrt_render and
+ * vrt_render_begin deal 8-row strips of the frame round-robin to the GPUs (one host thread and
+ * stream each, all samples of a strip on its GPU), and every GPU tone-maps and delivers the rows of
+ * its strips to the caller's buffers itself, over its own PCIe link (stored there by its frame
+ * kernel when the buffer comes from vrt_host_alloc).  vrt_render_poll reports the frame done when
+ * every GPU's part is; the statistics are summed, gpu_ms is the longest GPU's.  vrt_trace_pixel,
+ * vrt_trace_ray and path records run on the first GPU.  Option "multi_gather" = 1 gathers the
+ * strips on the first GPU over xGMI instead (peer-to-peer copies; an RCCL send/recv group with
+ * VRT_MULTI_RCCL=1 in the environment, a form no test has run on more than one GPU) and
+ * assembles, tone-maps and reads the frame back there.  vrt_render_begin_parts and the
+ * device-pointer calls are not offered on such a context. */
 int vrt_create_multi(int n_gpus, const int* devices, vrt_ctx** out);
 
 /* Study and test knobs by name ("sample_shift", "packet", "beam", "slab_fma", "quad_max", "stack_cap",
  * "wf_defer", "wf_refill", "wf_max_slots", "wf_any_cap", "wf_queue_cap", "builder", "collapse_parity",
- * "no_big", "xcd_remap", "block_compact", "zero_copy", "staged", "tile_sort", "fail_after_build"); none changes a result.
+ * "no_big", "xcd_remap", "block_compact", "zero_copy", "staged", "tile_sort", "multi_gather", "fail_after_build"); none changes a result.
  * builder / collapse_parity / no_big take effect at the next vrt_set_scene.  No counterpart in
  * the reference. */
 int vrt_set_option(vrt_ctx* ctx, const char* name, long long value);
@@ -349,9 +355,13 @@ int vrt_fetch_stats(vrt_ctx* ctx, vrt_stats* stats_out);
  * static device array of the library (one copy per GPU, 16 KiB + 8 bytes x
  * VRT_NOALLOC_MAX_OFFSETS = 528 KiB, held until the process ends).  Megakernel only
  * (mode VRT_MODE_WAVEFRONT is refused: its ray queues need a workspace) and
- * n_sets * spp <= VRT_NOALLOC_MAX_OFFSETS (else VRT_ERR_CAPACITY).  Every call on a GPU,
- * from whichever context, shares that GPU's array: calls that overlap on one GPU race, and
- * the counts of a call are gone once the next one starts. */
+ * n_sets * spp <= VRT_NOALLOC_MAX_OFFSETS (else VRT_ERR_CAPACITY).  A sampler table the GPU's
+ * array already holds is not uploaded again: such a call enqueues one fill and the kernel, with
+ * no host-side wait, and is what a capturing stream can take; a call with a new table under
+ * capture is refused (VRT_ERR_STATE: upload it with one uncaptured call first).  Every call on
+ * a GPU, from whichever context, shares that GPU's array: calls that overlap on one GPU race
+ * (also a call that finds its table there while the upload by another stream is still in
+ * flight), and the counts of a call are gone once the next one starts. */
 int vrt_render_device_noalloc(vrt_ctx* ctx, const vrt_params* params, void* rgba_dev,
                               void* hit_id_dev, void* stream);
 

@@ -28,6 +28,25 @@ static const size_t kStaticCtrBytes = kCtrBlock * sizeof(unsigned long long);
 static const size_t kStaticScratchBytes = kStaticCtrBytes + (size_t)VRT_NOALLOC_MAX_OFFSETS * sizeof(float2);
 static __device__ __align__(256) unsigned char g_vrt_static_scratch[kStaticScratchBytes];
 
+// What each GPU's copy of the array holds as its sampler table, kept on the host for comparison: a
+// call whose table is already there uploads nothing, and then consists of one fill and the kernel
+// launch only (which is also all a stream under graph capture can take).  Per GPU, not per context:
+// every context on a GPU shares that GPU's array.  The vectors get their full capacity once, in
+// vrt_create, so that the entry point itself never allocates host memory either.
+#define VRT_STATIC_MAX_DEVICES 64
+#include <mutex>
+struct StaticTable { std::mutex m; std::vector<float> host; size_t n = 0; };
+static StaticTable g_static_table[VRT_STATIC_MAX_DEVICES];
+
+// Clears the counter block of vrt_render_device_noalloc.  A kernel, not hipMemsetAsync: captured into
+// a graph, the fill node of ROCm 7.2 cleared the block on the first replay and wrote other values on
+// the following ones (the replayed frames were right, their ray counts were not); kernel nodes replay as recorded.
+__global__ __launch_bounds__(256) void k_clear_words(unsigned long long* p, unsigned n)
+{
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) p[i] = 0ull;
+}
+
 int vrt_fail(vrt_ctx* c, int code, const std::string& msg)
 {
     if (c) c->err = msg;
@@ -89,6 +108,7 @@ static void options_from_env(VrtOptions& o)
     o.quad_max = (int)geti("VRT_QUAD_MAX", -1);
     o.beam = (int)geti("VRT_BEAM", -1);
     o.slab_fma = (int)geti("VRT_SLAB_FMA", 1);
+    o.multi_gather = (int)geti("VRT_MULTI_GATHER", 0);
 }
 
 extern "C" int vrt_set_option(vrt_ctx* c, const char* name, long long value)
@@ -115,6 +135,7 @@ extern "C" int vrt_set_option(vrt_ctx* c, const char* name, long long value)
     else if (n == "stack_cap") { if (value < 0 || value > VRT_TRAV_STACK) return fail(c, VRT_ERR_INVALID, "stack_cap: 0..VRT_TRAV_STACK"); o.stack_cap = (int)value; }
     else if (n == "quad_max") { if (value < -1 || value > 64) return fail(c, VRT_ERR_INVALID, "quad_max: -1..64"); o.quad_max = (int)value; }
     else if (n == "fail_after_build") o.fail_after_build = value != 0;
+    else if (n == "multi_gather") o.multi_gather = value != 0;
     else if (n == "beam") { if (value < -1 || value > 2) return fail(c, VRT_ERR_INVALID, "beam: -1, 0, 1 or 2"); o.beam = (int)value; }
     else if (n == "packet") { if (value < -1 || value > 2) return fail(c, VRT_ERR_INVALID, "packet: -1, 0, 1 or 2"); o.packet = (int)value; }
     else return fail(c, VRT_ERR_INVALID, "unknown option " + n);
@@ -183,6 +204,10 @@ extern "C" int vrt_create(int device, vrt_ctx** out)
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return VRT_ERR_NO_DEVICE;
     if (device < 0 || device >= n) return VRT_ERR_INVALID;
+    if (device < VRT_STATIC_MAX_DEVICES) {
+        std::lock_guard<std::mutex> g(g_static_table[device].m);
+        g_static_table[device].host.reserve(2 * (size_t)VRT_NOALLOC_MAX_OFFSETS);
+    }
     vrt_ctx* c = new vrt_ctx();
     c->device = device;
     memset(&c->sb.scene, 0, sizeof c->sb.scene);
@@ -853,6 +878,10 @@ static int plan_tile_order(vrt_ctx* c, DevParams& P, hipStream_t stream, bool* s
     if (!same || (++c->tile_age & period_mask) == 0) {
         P.tile_cost = c->d_tile_cost;
         *sort_after = true;
+        // The order on the device stops being valid here and becomes valid again when the sort
+        // behind this frame has been enqueued: should the launch or the sort fail, the next frame
+        // must not look its tiles up in an order made for another layout.
+        c->tile_valid = false;
         memcpy(c->tile_sig, sig, sizeof sig);
     }
     c->tile_stream = stream;
@@ -1058,13 +1087,17 @@ static int copy_rows_out(vrt_ctx* c, const DevParams& P, float* rgba_out, int32_
 // The device's address of `p` when [p, p + bytes) lies inside a buffer of vrt_host_alloc, else null.
 // Such a buffer is page-locked and mapped into the device's address space, so a kernel can store
 // to it directly.
+// (The buffers of a multi-GPU context belong to the context the caller holds; page-locked host
+// memory is mapped into every GPU's address space, and each GPU asks for its own view of it with
+// itself as the current device.)
 static void* device_view_of_host_alloc(vrt_ctx* c, void* p, size_t bytes)
 {
-    for (size_t i = 0; i < c->host_allocs.size(); ++i) {
-        char* b = (char*)c->host_allocs[i];
-        if ((char*)p >= b && (char*)p + bytes <= b + c->host_alloc_bytes[i]) {
+    const vrt_ctx* owner = c->host_owner ? c->host_owner : c;
+    for (size_t i = 0; i < owner->host_allocs.size(); ++i) {
+        char* b = (char*)owner->host_allocs[i];
+        if ((char*)p >= b && (char*)p + bytes <= b + owner->host_alloc_bytes[i]) {
             void* d = nullptr;
-            if (hipHostGetDevicePointer(&d, c->host_allocs[i], 0) != hipSuccess || !d) return nullptr;
+            if (hipHostGetDevicePointer(&d, owner->host_allocs[i], 0) != hipSuccess || !d) { (void)hipGetLastError(); return nullptr; }
             return (char*)d + ((char*)p - b);
         }
     }
@@ -1201,11 +1234,10 @@ extern "C" int vrt_render(vrt_ctx* c, const vrt_params* p, float* rgba_out, int3
     return VRT_OK;
 }
 
-extern "C" int vrt_render_begin(vrt_ctx* c, const vrt_params* p, float* rgba_out, int32_t* hit_id_out)
+// vrt_render_begin on this context's own GPU: the frame (or the strips p names) and its copies to
+// the caller's buffers are enqueued, ev_done marks their end.
+int vrt_begin_one(vrt_ctx* c, const vrt_params* p, float* rgba_out, int32_t* hit_id_out)
 {
-    if (!c || !p || !rgba_out) return fail(c, VRT_ERR_INVALID, "null argument");
-    if (c->multi) return fail(c, VRT_ERR_INVALID, "a multi-GPU context renders with the blocking vrt_render");
-    if (p->n_record_pixels != 0) return fail(c, VRT_ERR_INVALID, "path recording needs the blocking vrt_render");
     DevParams P;
     int rc = begin_frame(c, p, rgba_out, hit_id_out, &P);
     if (rc) return rc;
@@ -1213,6 +1245,14 @@ extern "C" int vrt_render_begin(vrt_ctx* c, const vrt_params* p, float* rgba_out
     c->pending = true;
     c->parts_pending = 0;
     return VRT_OK;
+}
+
+extern "C" int vrt_render_begin(vrt_ctx* c, const vrt_params* p, float* rgba_out, int32_t* hit_id_out)
+{
+    if (!c || !p || !rgba_out) return fail(c, VRT_ERR_INVALID, "null argument");
+    if (p->n_record_pixels != 0) return fail(c, VRT_ERR_INVALID, "path recording needs the blocking vrt_render");
+    if (c->multi) return vrt_multi_begin(c, p, rgba_out, hit_id_out);
+    return vrt_begin_one(c, p, rgba_out, hit_id_out);
 }
 
 // The frame in n_parts strip sets, each rendered, copied to the caller's buffers (its rows only)
@@ -1263,15 +1303,22 @@ extern "C" int vrt_render_begin_parts(vrt_ctx* c, const vrt_params* p, float* rg
     return VRT_OK;
 }
 
-extern "C" int vrt_render_poll(vrt_ctx* c, int* done)
+int vrt_poll_one(vrt_ctx* c, int* done)
 {
-    if (!c || !done) return fail(c, VRT_ERR_INVALID, "null argument");
     if (!c->pending) return fail(c, VRT_ERR_STATE, "no frame in flight");
     HIPCHK(c, hipSetDevice(c->device));
     hipError_t e = hipEventQuery(c->ev_done);
     if (e == hipSuccess) { *done = 1; return VRT_OK; }
     if (e == hipErrorNotReady) { *done = 0; (void)hipGetLastError(); return VRT_OK; }
     return fail(c, VRT_ERR_HIP, std::string("hipEventQuery: ") + hipGetErrorString(e));
+}
+
+extern "C" int vrt_render_poll(vrt_ctx* c, int* done)
+{
+    if (!c || !done) return fail(c, VRT_ERR_INVALID, "null argument");
+    if (!c->pending) return fail(c, VRT_ERR_STATE, "no frame in flight");
+    if (c->multi) return vrt_multi_poll(c, done);
+    return vrt_poll_one(c, done);
 }
 
 extern "C" int vrt_render_poll_parts(vrt_ctx* c, int* parts_done)
@@ -1289,9 +1336,8 @@ extern "C" int vrt_render_poll_parts(vrt_ctx* c, int* parts_done)
     return VRT_OK;
 }
 
-extern "C" int vrt_render_end(vrt_ctx* c, vrt_stats* stats_out)
+int vrt_end_one(vrt_ctx* c, vrt_stats* stats_out)
 {
-    if (!c) return VRT_ERR_INVALID;
     if (!c->pending) return fail(c, VRT_ERR_STATE, "no frame in flight");
     HIPCHK(c, hipSetDevice(c->device));
     c->pending = false;
@@ -1299,6 +1345,14 @@ extern "C" int vrt_render_end(vrt_ctx* c, vrt_stats* stats_out)
     HIPCHK(c, hipEventSynchronize(c->ev_done));
     if (stats_out) return read_stats(c, stats_out);
     return check_wf_overflow(c);
+}
+
+extern "C" int vrt_render_end(vrt_ctx* c, vrt_stats* stats_out)
+{
+    if (!c) return VRT_ERR_INVALID;
+    if (!c->pending) return fail(c, VRT_ERR_STATE, "no frame in flight");
+    if (c->multi) return vrt_multi_end(c, stats_out);
+    return vrt_end_one(c, stats_out);
 }
 
 // vrt_render_device enqueues and returns: a wavefront frame whose queues overflowed is reported
@@ -1362,15 +1416,33 @@ extern "C" int vrt_render_device_noalloc(vrt_ctx* c, const vrt_params* p, void* 
     unsigned long long* ctr = (unsigned long long*)c->static_scratch;
     float2* offs = (float2*)(c->static_scratch + kStaticCtrBytes);
     if (n_off) {
-        // through the context's page-locked staging, once the copy of the previous call has left it
-        if (c->static_used) HIPCHK(c, hipEventSynchronize(c->ev_static));
-        memcpy(c->static_stage, p->offsets, n_off * sizeof(float2));
-        HIPCHK(c, hipMemcpyAsync(offs, c->static_stage, n_off * sizeof(float2), hipMemcpyHostToDevice, s));
-        HIPCHK(c, hipEventRecord(c->ev_static, s));
-        c->static_used = true;
+        if (c->device >= VRT_STATIC_MAX_DEVICES) return fail(c, VRT_ERR_CAPACITY, "device ordinal beyond VRT_STATIC_MAX_DEVICES");
+        StaticTable& T = g_static_table[c->device];
+        std::lock_guard<std::mutex> g(T.m);
+        if (T.n != n_off || memcmp(T.host.data(), p->offsets, n_off * sizeof(float2)) != 0) {
+            // A table the array does not hold yet goes through the context's page-locked staging, once
+            // the copy of this context's previous upload has left it.  That wait is a host-side
+            // synchronisation, which a capturing stream does not allow: under capture the table has
+            // to be one an earlier, uncaptured call has put there.
+            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(s, &cap) != hipSuccess) (void)hipGetLastError();
+            if (cap != hipStreamCaptureStatusNone)
+                return fail(c, VRT_ERR_STATE, "vrt_render_device_noalloc under stream capture needs the sampler table of an earlier, "
+                                              "uncaptured call on this GPU (a new table is uploaded through a host-side wait)");
+            if (c->static_used) HIPCHK(c, hipEventSynchronize(c->ev_static));
+            memcpy(c->static_stage, p->offsets, n_off * sizeof(float2));
+            T.n = 0;   // not valid until the copy has been enqueued
+            HIPCHK(c, hipMemcpyAsync(offs, c->static_stage, n_off * sizeof(float2), hipMemcpyHostToDevice, s));
+            HIPCHK(c, hipEventRecord(c->ev_static, s));
+            c->static_used = true;
+            T.host.assign(p->offsets, p->offsets + 2 * n_off);   // within the capacity reserved by vrt_create
+            T.n = n_off;
+        }
         P.offsets = offs;
     }
-    HIPCHK(c, hipMemsetAsync(ctr, 0, kStaticCtrBytes, s));   // the array keeps the last call's counts
+    // the array keeps the last call's counts
+    hipLaunchKernelGGL(k_clear_words, dim3((unsigned)((kCtrBlock + 255) / 256)), dim3(256), 0, s, ctr, (unsigned)kCtrBlock);
+    HIPCHK(c, hipGetLastError());
     c->timed = false;
     P.flags |= p->flags & VRT_OUT_LINEAR_RGB;
     return enqueue_frame(c, p, P, (float4*)rgba_dev, (int*)hit_id_dev, s, ctr, false);   // ordering tiles would allocate

@@ -1182,11 +1182,13 @@ static hipError_t build_sah_device(int n, const float4* d_pbox, const unsigned* 
     SCHK(hipMalloc(&split, (size_t)max_big * sizeof(BigSplit)));
     SCHK(hipMalloc(&level_state, state_bytes));
     hipLaunchKernelGGL(k_sah_refs, dim3((n + 255) / 256), dim3(256), 0, stream, n, d_pbox, ref_a);
+    SCHK(hipGetLastError());
     {
         int n_in = 0, n_big = 0, n_chunks = 0, n_small = 0;
         if (n > VRT_SAH_BIG) {
             n_big = 1; n_chunks = (n + VRT_SAH_CHUNK - 1) / VRT_SAH_CHUNK;
             hipLaunchKernelGGL(k_big_root, dim3((n_chunks + 255) / 256), dim3(256), 0, stream, n, d_cb, big_a, chunk_a);
+            SCHK(hipGetLastError());
         } else {
             const SahTask root = {0, n, 0, -1};
             SCHK(hipMemcpyAsync(n <= VRT_SAH_SMALL ? qs_a : q_a, &root, sizeof root, hipMemcpyHostToDevice, stream));
@@ -1200,20 +1202,30 @@ static hipError_t build_sah_device(int n, const float4* d_pbox, const unsigned* 
                 unsigned* bins = level_state;
                 BigOut* outs = (BigOut*)(level_state + bins_words);
                 SCHK(hipMemsetAsync(level_state, 0, state_bytes, stream));
+                // a launch that fails (a grid too large, say) must end the build here: the host would
+                // otherwise read the counts of a level that never ran
                 hipLaunchKernelGGL(k_big_bin, dim3(n_chunks), dim3(256), 0, stream, level, ref_a, big_a, chunk_a, bins);
+                SCHK(hipGetLastError());
                 hipLaunchKernelGGL(k_big_count, dim3(n_chunks), dim3(256), 0, stream, level, ref_a, big_a, chunk_a, bins, split,
                                    left_count);
+                SCHK(hipGetLastError());
                 hipLaunchKernelGGL(k_big_scatter, dim3(n_chunks), dim3(256), 0, stream, ref_a, ref_b, big_a, chunk_a, split,
                                    left_count, outs);
+                SCHK(hipGetLastError());
                 hipLaunchKernelGGL(k_big_finish, dim3((n_big + 63) / 64), dim3(64), 0, stream, n_big, big_a, split, outs, d_nodes,
                                    d_parent, d_leaf_parent, q_b, qs_b, counts, big_b, chunk_b);
+                SCHK(hipGetLastError());
             }
-            if (n_in > 0)
+            if (n_in > 0) {
                 hipLaunchKernelGGL((k_sah_level<64>), dim3((n_in + 3) / 4), dim3(256), 0, stream, level, ref_a, ref_b, q_a, n_in, q_b,
                                    qs_b, counts, d_nodes, d_parent, d_leaf_parent);
-            if (n_small > 0)
+                SCHK(hipGetLastError());
+            }
+            if (n_small > 0) {
                 hipLaunchKernelGGL((k_sah_level<16>), dim3((n_small + 15) / 16), dim3(256), 0, stream, level, ref_a, ref_b, qs_a,
                                    n_small, q_b, qs_b, counts, d_nodes, d_parent, d_leaf_parent);
+                SCHK(hipGetLastError());
+            }
             SCHK(hipMemcpyAsync(h, counts, 4 * sizeof(int), hipMemcpyDeviceToHost, stream));
             SCHK(hipStreamSynchronize(stream));
             n_in = h[0]; n_big = h[1]; n_chunks = h[2]; n_small = h[3];

@@ -37,6 +37,7 @@ struct VrtOptions {
     int tile_sort = 1;          // tree scenes, megakernel: tiles dispatched most expensive first, by the costs an earlier frame measured
     int zero_copy = 1;          // frames into a vrt_host_alloc buffer are stored there by the frame kernel itself
     int fail_after_build = 0;   // tests: vrt_set_scene reports a failure after uploads and tree build have succeeded
+    int multi_gather = 0;       // multi-GPU context: 0 = every GPU delivers its strips to the caller's buffer itself, over its own PCIe link; 1 = strips gathered on the first GPU over xGMI and assembled there
 };
 
 // Everything vrt_set_scene uploads or builds.  A new scene is assembled in a fresh SceneBufs and
@@ -165,6 +166,9 @@ struct vrt_ctx {
     bool timed = false;
     // several GPUs behind this context (vrt_create_multi); null for a one-GPU context
     VrtMulti* multi = nullptr;
+    // the context whose vrt_host_alloc buffers this one may store frames into: the context the
+    // caller holds, for the other GPUs' contexts of a multi-GPU context; null = its own
+    vrt_ctx* host_owner = nullptr;
 };
 
 int vrt_fail(vrt_ctx* c, int code, const std::string& msg);
@@ -186,11 +190,17 @@ int vrt_swap_scene_one(vrt_ctx* c, SceneBufs& nb);
 int vrt_render_device_one(vrt_ctx* c, const vrt_params* p, void* rgba_dev, void* hit_id_dev, void* stream);
 int vrt_record_pixels_one(vrt_ctx* c, const vrt_params* p);
 int vrt_read_stats_one(vrt_ctx* c, vrt_stats* s);
+int vrt_begin_one(vrt_ctx* c, const vrt_params* p, float* rgba_out, int32_t* hit_id_out);
+int vrt_poll_one(vrt_ctx* c, int* done);
+int vrt_end_one(vrt_ctx* c, vrt_stats* stats_out);
 
 // vrt_multi.hip: the entry points of include/vrt.h on a context that spans several GPUs.
 int vrt_multi_init(vrt_ctx* c, int n_gpus, const int* devices);
 int vrt_multi_set_scene(vrt_ctx* c, const vrt_scene_desc* d);
 int vrt_multi_set_camera(vrt_ctx* c, const vrt_camera* cam);
 int vrt_multi_render(vrt_ctx* c, const vrt_params* p, float* rgba_out, int32_t* hit_id_out, vrt_stats* stats_out);
+int vrt_multi_begin(vrt_ctx* c, const vrt_params* p, float* rgba_out, int32_t* hit_id_out);
+int vrt_multi_poll(vrt_ctx* c, int* done);
+int vrt_multi_end(vrt_ctx* c, vrt_stats* stats_out);
 int vrt_multi_set_option(vrt_ctx* c, const char* name, long long value);
 void vrt_multi_destroy(vrt_ctx* c);

@@ -4,18 +4,22 @@
 //
 //   scene, camera   replicated: every GPU holds all primitives and builds its own tree.
 //   frame           strips of tile_rows rows, strip s rendered by GPU s % n with all its samples
-//                   (RayTracerUnity.cs:578-592 needs no exchange between pixels); each GPU writes
-//                   the averaged radiance of its strips, 3 floats per pixel, rows packed.
-//   gather          one RCCL group of send/recv pairs moves the strips of GPUs 1..n-1 over their
-//                   xGMI links into one buffer on the first GPU (its own strips are rendered into
-//                   that buffer directly); hit ids travel the same way when asked for.
-//   assembly        one kernel on the first GPU puts the rows back in frame order and tone-maps
-//                   (Util/RayTraceUtility.cs:409-422), then the frame is copied to the caller.
+//                   (RayTracerUnity.cs:578-592 needs no exchange between pixels).
+//   delivery        every GPU tone-maps its own pixels (Util/RayTraceUtility.cs:409-422 looks at one
+//                   pixel at a time) and delivers the rows of its strips to the caller's buffer
+//                   itself, over its own PCIe link: stored there by its frame kernel when the buffer
+//                   comes from vrt_host_alloc, else copied strip by strip.  Nothing passes through
+//                   the first GPU, so the frame's way to the host is n links wide, and the
+//                   non-blocking calls (vrt_render_begin / poll / end) work as on one GPU.
+//   gather          option multi_gather = 1 (study, and hosts that want the strips on one GPU):
+//                   the GPUs write the averaged radiance of their strips, 3 floats per pixel, rows
+//                   packed; the strips of GPUs 1..n-1 travel over their xGMI links into one buffer
+//                   on the first GPU (peer-to-peer copies; one RCCL group of send/recv pairs when
+//                   VRT_MULTI_RCCL=1 is set), one kernel there puts the rows back in frame order
+//                   and tone-maps, then the frame is copied to the caller.
 //
-// One host thread per GPU enqueues that GPU's work; RCCL is loaded when the first multi-GPU
-// context is created, so a host that renders on one GPU never loads it.  When the devices of a
-// context are not all different (tests on a one-GPU machine) or RCCL is not available, the strips
-// travel with peer-to-peer copies instead.
+// One host thread per GPU enqueues that GPU's work.  RCCL is loaded only when asked for, so a host
+// that renders on one GPU, or delivers per GPU, never loads it.
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 #include <rccl/rccl.h>
@@ -190,6 +194,7 @@ int vrt_multi_init(vrt_ctx* c, int n_gpus, const int* devices)
         int rc = vrt_create(m->dev[k], &m->sub[k]);
         if (rc != VRT_OK) return vrt_fail(c, rc, "vrt_create failed on GPU " + std::to_string(m->dev[k]));
         m->sub[k]->opt = c->opt;
+        m->sub[k]->host_owner = c;
         m->workers[k] = new Worker();
         HIPCHK(c, hipSetDevice(m->dev[k]));
         HIPCHK(c, hipEventCreateWithFlags(&m->ev_sent[k], hipEventDisableTiming));
@@ -203,8 +208,11 @@ int vrt_multi_init(vrt_ctx* c, int n_gpus, const int* devices)
         }
     }
     HIPCHK(c, hipSetDevice(c->device));
-    const char* force_p2p = getenv("VRT_MULTI_P2P");
-    if (n_gpus > 1 && distinct && !(force_p2p && atoi(force_p2p)) && rccl().ok) {
+    // The gather's RCCL form has never run on more than one GPU (the pool this library is developed
+    // on hands out one GPU at a time), so it has to be asked for; peer-to-peer copies are the
+    // tested form.
+    const char* want_rccl = getenv("VRT_MULTI_RCCL");
+    if (n_gpus > 1 && distinct && want_rccl && atoi(want_rccl) && rccl().ok) {
         m->comm.assign(n_gpus, nullptr);
         ncclResult_t r = rccl().CommInitAll(m->comm.data(), n_gpus, m->dev.data());
         if (r != ncclSuccess) { m->comm.clear(); (void)hipGetLastError(); }   // peer-to-peer copies instead
@@ -270,13 +278,111 @@ int vrt_multi_set_camera(vrt_ctx* c, const vrt_camera* cam)
     return rc;
 }
 
-int vrt_multi_render(vrt_ctx* c, const vrt_params* p, float* rgba_out, int32_t* hit_id_out, vrt_stats* stats_out)
+// Waits for whatever the GPUs of the context have been given (an error path: a call that fails
+// after some GPUs have enqueued their part must not return with work in flight on the caller's buffers).
+static void drain_all(VrtMulti* m)
 {
-    VrtMulti* m = c->multi;
+    for (int k = 0; k < m->n; ++k) {
+        if (!m->sub[k]) continue;
+        if (hipSetDevice(m->dev[k]) == hipSuccess) (void)hipStreamSynchronize(m->sub[k]->stream);
+        m->sub[k]->pending = false; m->sub[k]->parts_pending = 0;
+    }
+    (void)hipGetLastError();
+    (void)hipSetDevice(m->dev[0]);
+}
+
+static int multi_check(vrt_ctx* c, const vrt_params* p)
+{
     if (!c->have_scene || !c->have_cam) return vrt_fail(c, VRT_ERR_STATE, "scene or camera not set");
     if (c->pending) return vrt_fail(c, VRT_ERR_STATE, "a frame started with vrt_render_begin is still in flight");
     if (p->tile_count > 1 || p->compact_rows) return vrt_fail(c, VRT_ERR_INVALID, "a multi-GPU context cuts the frame itself");
     if (p->flags & VRT_OUT_LINEAR_RGB) return vrt_fail(c, VRT_ERR_INVALID, "VRT_OUT_LINEAR_RGB is an output format of vrt_render_device");
+    return VRT_OK;
+}
+
+// vrt_render_begin on every GPU: GPU k enqueues the strips s with s % n == k and their way to the
+// caller's buffers on its own stream (vrt_begin_one with the strip parameters a rank of a
+// multi-process job would pass).  The frame is complete when every GPU's is.
+int vrt_multi_begin(vrt_ctx* c, const vrt_params* p, float* rgba_out, int32_t* hit_id_out)
+{
+    VrtMulti* m = c->multi;
+    int rc = multi_check(c, p);
+    if (rc != VRT_OK) return rc;
+    const int n = m->n, rows = p->tile_rows > 0 ? p->tile_rows : 8;
+    rc = on_all(m, [&](int k) -> int {
+        vrt_params q = *p;
+        q.tile_index = k; q.tile_count = n; q.tile_rows = rows; q.compact_rows = 0;
+        q.n_record_pixels = 0; q.record_pixels = nullptr;
+        return vrt_begin_one(m->sub[k], &q, rgba_out, hit_id_out);
+    });
+    if (rc != VRT_OK) { copy_error(c, m); drain_all(m); return rc; }
+    (void)hipSetDevice(c->device);
+    return VRT_OK;
+}
+
+int vrt_multi_poll(vrt_ctx* c, int* done)
+{
+    VrtMulti* m = c->multi;
+    *done = 1;
+    for (int k = 0; k < m->n; ++k) {
+        int d = 0;
+        int rc = vrt_poll_one(m->sub[k], &d);
+        if (rc != VRT_OK) { if (k > 0) copy_error(c, m); (void)hipSetDevice(c->device); return rc; }
+        if (!d) { *done = 0; break; }
+    }
+    (void)hipSetDevice(c->device);
+    return VRT_OK;
+}
+
+// Statistics are the sum over the GPUs; gpu_ms is the longest of their device times, which run side by side.
+int vrt_multi_end(vrt_ctx* c, vrt_stats* stats_out)
+{
+    VrtMulti* m = c->multi;
+    vrt_stats sum;
+    memset(&sum, 0, sizeof sum);
+    int rc = VRT_OK;
+    for (int k = 0; k < m->n; ++k) {
+        vrt_stats s;
+        memset(&s, 0, sizeof s);
+        const int r = vrt_end_one(m->sub[k], &s);
+        if (r != VRT_OK) { if (rc == VRT_OK) { rc = r; if (k > 0) copy_error(c, m); } continue; }
+        for (int q = 0; q < VRT_RAY_CLASSES; ++q) sum.rays[q] += s.rays[q];
+        sum.nodes_visited += s.nodes_visited; sum.prims_tested += s.prims_tested;
+        sum.pixels += s.pixels;
+        if (s.gpu_ms > sum.gpu_ms) sum.gpu_ms = s.gpu_ms;
+        if (k == 0) { sum.bvh_build_ms = s.bvh_build_ms; sum.bvh_nodes = s.bvh_nodes; sum.mode_used = s.mode_used; }
+    }
+    (void)hipSetDevice(c->device);
+    if (rc != VRT_OK) { drain_all(m); return rc; }
+    c->last_pixels = sum.pixels;
+    if (stats_out) *stats_out = sum;
+    return VRT_OK;
+}
+
+static int multi_render_gather(vrt_ctx* c, const vrt_params* p, float* rgba_out, int32_t* hit_id_out, vrt_stats* stats_out);
+
+int vrt_multi_render(vrt_ctx* c, const vrt_params* p, float* rgba_out, int32_t* hit_id_out, vrt_stats* stats_out)
+{
+    VrtMulti* m = c->multi;
+    int rc = multi_check(c, p);
+    if (rc != VRT_OK) return rc;
+    if (c->opt.multi_gather) {
+        rc = multi_render_gather(c, p, rgba_out, hit_id_out, stats_out);
+        if (rc != VRT_OK) drain_all(m);
+        return rc;
+    }
+    rc = vrt_multi_begin(c, p, rgba_out, hit_id_out);
+    if (rc != VRT_OK) return rc;
+    rc = vrt_multi_end(c, stats_out);
+    if (rc != VRT_OK) return rc;
+    if (p->n_record_pixels > 0) return vrt_record_pixels_one(c, p);   // the scene is replicated: the first GPU traces them
+    return VRT_OK;
+}
+
+// The frame with its strips gathered on the first GPU (option multi_gather).
+static int multi_render_gather(vrt_ctx* c, const vrt_params* p, float* rgba_out, int32_t* hit_id_out, vrt_stats* stats_out)
+{
+    VrtMulti* m = c->multi;
     const int W = c->cam.width, H = c->cam.height, n = m->n;
     const int rows = p->tile_rows > 0 ? p->tile_rows : 8;
     const bool want_hits = hit_id_out != nullptr;

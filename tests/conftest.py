@@ -47,3 +47,17 @@ def vrt_opts(vrt_ctx):
     yield set_option
     for k, v in OPTION_DEFAULTS.items():
         vrt_ctx.set_option(k, v)
+
+
+def assert_frame_matches_oracle(rgba, hit, rays, oracle_frame, tol=1.0 / 255.0):
+    """The parity bar of every frame test: primary hit ids and per-class ray counts bit-exact, RGB
+    within 1/255 of the oracle's frame (NaN where the oracle has NaN)."""
+    import numpy as np
+    o_rgba, o_hit, o_rays = oracle_frame
+    if hit is not None:
+        assert np.array_equal(hit, o_hit), f"{np.count_nonzero(hit != o_hit)} primary hit ids differ from the oracle"
+    if rays is not None:
+        assert np.array_equal(np.array(list(rays), np.uint64), o_rays), "ray counts differ from the oracle"
+    both_nan = np.isnan(rgba) & np.isnan(o_rgba)
+    err = np.abs(np.where(both_nan, 0, rgba) - np.where(both_nan, 0, o_rgba))
+    assert not np.isnan(err).any() and err.max() <= tol, float(err.max())

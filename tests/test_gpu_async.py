@@ -1,5 +1,8 @@
-"""Non-blocking frame API: begin / poll / end must deliver exactly the frame vrt_render delivers,
-strip by strip if asked, and must refuse other work on the context while a frame is in flight."""
+"""Non-blocking frame API (replaces the per-sample `yield return null` of
+Assets/Scripts/RayTracer/RayTracerUnity.cs:588 and the whole-texture upload of :461-477): begin /
+poll / end must deliver the oracle's frame (hit ids and ray counts exact, RGB within 1/255), strip by
+strip if asked, bit-identical to the blocking call, and must refuse other work on the context while
+a frame is in flight."""
 import time
 
 import numpy as np
@@ -7,8 +10,18 @@ import pytest
 
 import raytracing_amd as ra
 from raytracing_amd import abi, host
+from conftest import assert_frame_matches_oracle
 
 pytestmark = pytest.mark.gpu
+_ORACLE = {}
+
+
+def _oracle_frame(oracle_mod, kw):
+    """The oracle's frame of _setup()'s scene, rendered once per session."""
+    if "frame" not in _ORACLE:
+        scene, cam = ra.random_spheres_scene(2000, seed=9), ra.random_spheres_camera(320, 200)
+        _ORACLE["frame"] = oracle_mod.render(scene, cam, ra.Params(**kw).c, n_threads=8)
+    return _ORACLE["frame"]
 
 
 def _setup(ctx):
@@ -19,7 +32,7 @@ def _setup(ctx):
     return dict(spp=4, offsets=offs, seed=3, max_depth=5, rng=200.0)
 
 
-def test_begin_poll_end_equals_render(vrt_ctx):
+def test_begin_poll_end_equals_render(vrt_ctx, oracle_mod):
     kw = _setup(vrt_ctx)
     ref, ref_hit, ref_st = vrt_ctx.render(ra.Params(**kw))
     rgba = np.zeros_like(ref)
@@ -32,6 +45,7 @@ def test_begin_poll_end_equals_render(vrt_ctx):
         polls += 1
         assert time.time() < deadline
     st = vrt_ctx.render_end()
+    assert_frame_matches_oracle(rgba, hit, st.rays, _oracle_frame(oracle_mod, kw))
     assert np.array_equal(rgba, ref, equal_nan=True) and np.array_equal(hit, ref_hit)
     assert list(st.rays) == list(ref_st.rays) and st.gpu_ms > 0
 
@@ -56,7 +70,7 @@ def test_calls_are_refused_while_a_frame_is_in_flight(vrt_ctx):
     assert np.array_equal(rgba, ref, equal_nan=True)
 
 
-def test_progressive_strips(vrt_ctx):
+def test_progressive_strips(vrt_ctx, oracle_mod):
     """The frame delivered strip by strip (one begin/end per strip set) into one buffer equals the
     frame rendered at once; rows of later strips stay untouched until their turn."""
     kw = _setup(vrt_ctx)
@@ -64,12 +78,14 @@ def test_progressive_strips(vrt_ctx):
     rgba = np.full_like(ref, -1.0)
     hit = np.full_like(ref_hit, -7)
     n = 5
+    rays = np.zeros(abi.VRT_RAY_CLASSES, np.uint64)
     for k in range(n):
         prm = ra.Params(tile_index=k, tile_count=n, tile_rows=8, **kw)
         vrt_ctx.render_begin(prm, rgba, hit)
-        vrt_ctx.render_end()
+        rays += np.array(vrt_ctx.render_end().rays[:], np.uint64)
         rows_done = [h for h in range(200) if (h // 8) % n <= k]
         rows_left = [h for h in range(200) if (h // 8) % n > k]
         assert np.array_equal(rgba[rows_done], ref[rows_done], equal_nan=True)
         assert (rgba[rows_left] == -1.0).all() and (hit[rows_left] == -7).all()
     assert np.array_equal(hit, ref_hit)
+    assert_frame_matches_oracle(rgba, hit, rays, _oracle_frame(oracle_mod, kw))   # the strips' ray counts add up to the frame's

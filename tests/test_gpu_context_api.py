@@ -8,8 +8,17 @@ import pytest
 
 import raytracing_amd as ra
 from raytracing_amd import abi, host
+from conftest import assert_frame_matches_oracle
 
 pytestmark = pytest.mark.gpu
+_ORACLE = {}
+
+
+def _oracle_frame(oracle_mod, key, scene, cam, kw):
+    """Oracle frames are rendered once per session and scene."""
+    if key not in _ORACLE:
+        _ORACLE[key] = oracle_mod.render(scene, cam, ra.Params(**kw).c, n_threads=8)
+    return _ORACLE[key]
 
 
 def _spheres(w=160, h=93):
@@ -18,14 +27,17 @@ def _spheres(w=160, h=93):
             dict(spp=4, offsets=offs, seed=3, max_depth=5, rng=200.0))
 
 
+@pytest.mark.parametrize("gather", [0, 1])
 @pytest.mark.parametrize("n", [1, 2, 3])
 @pytest.mark.parametrize("which", ["teaching", "spheres"])
-def test_multi_gpu_context_equals_one_gpu(vrt_ctx, oracle_mod, which, n):
-    """vrt_create_multi renders strips on every GPU of the context, gathers them on the first and
-    tone-maps there; the frame, the hit ids and the ray counts are those of the one-GPU context.
-    A one-GPU box stands in for the node by naming GPU 0 several times (the strips then travel by
-    peer-to-peer copies instead of RCCL): strip bookkeeping, ragged last strips, assembly, statistics
-    and path records all run as they do across GPUs."""
+def test_multi_gpu_context_equals_one_gpu(vrt_ctx, oracle_mod, which, n, gather):
+    """vrt_create_multi renders strips on every GPU of the context; every GPU delivers its strips
+    to the caller's buffer itself (gather = 0), or the strips are gathered on the first GPU and
+    tone-mapped there (option multi_gather); the frame, the hit ids and the ray counts are the
+    oracle's and, bit for bit, those of the one-GPU context.  A one-GPU box stands in for the node
+    by naming GPU 0 several times (gathered strips then travel by peer-to-peer copies): strip
+    bookkeeping, ragged last strips, assembly, statistics, path records, frames into page-locked
+    buffers of the context and the non-blocking calls all run as they do across GPUs."""
     if which == "teaching":
         scene, cam, kw = ra.teaching_scene(), ra.teaching_camera(150, 85), dict(spp=1, max_depth=5)
     else:
@@ -33,12 +45,15 @@ def test_multi_gpu_context_equals_one_gpu(vrt_ctx, oracle_mod, which, n):
     vrt_ctx.set_scene(scene)
     vrt_ctx.set_camera(cam)
     want, want_hit, want_st = vrt_ctx.render(ra.Params(**kw))
+    oracle_frame = _oracle_frame(oracle_mod, which, scene, cam, kw)
     m = host.Context(devices=[0] * n)
     try:
+        m.set_option("multi_gather", gather)
         m.set_scene(scene)
         m.set_camera(cam)
         for rows in (8, 5):
             got, got_hit, st = m.render(ra.Params(tile_rows=rows, **kw))
+            assert_frame_matches_oracle(got, got_hit, st.rays, oracle_frame)
             assert np.array_equal(got, want, equal_nan=True) and np.array_equal(got_hit, want_hit)
             assert list(st.rays) == list(want_st.rays) and st.pixels == cam.width * cam.height
             assert st.gpu_ms > 0
@@ -53,11 +68,44 @@ def test_multi_gpu_context_equals_one_gpu(vrt_ctx, oracle_mod, which, n):
         rsegs, rcounts = ref.record(px, 64)
         vrt_ctx.render(ref)
         assert list(counts) == list(rcounts) and min(counts) > 0
+        for k, pix in enumerate(px):   # the recorded ray trees are the oracle's
+            _, _, o_segs, o_n, _ = oracle_mod.trace_pixel(scene, cam, ra.Params(**kw).c, pix // cam.width, pix % cam.width, -1, 64)
+            assert counts[k] == o_n
+            for j in range(min(o_n, 64)):
+                a, b = segs[k * 64 + j], o_segs[j]
+                assert (a.kind, a.depth, a.hit_prim, a.sample) == (b.kind, b.depth, b.hit_prim, b.sample)
+                assert list(a.origin) == list(b.origin) and list(a.end) == list(b.end)
         for k, n_seg in enumerate(counts):   # entries beyond a pixel's count are not written
             assert bytes(segs)[k * 64 * 40:(k * 64 + n_seg) * 40] == bytes(rsegs)[k * 64 * 40:(k * 64 + n_seg) * 40]
+        # a frame into a page-locked buffer of the context: every GPU's kernel stores its strips there
+        # itself; the rest of the allocation keeps what the caller had there
+        big = m.host_alloc((cam.height + 6, cam.width, 4), np.float32)
+        big[:] = -3.0
+        out = big[3:3 + cam.height]
+        _, got_hit, st = m.render(ra.Params(tile_rows=5, **kw), rgba=out)
+        assert np.array_equal(out, want, equal_nan=True) and np.array_equal(got_hit, want_hit)
+        assert (big[:3] == -3.0).all() and (big[3 + cam.height:] == -3.0).all() and list(st.rays) == list(want_st.rays)
+        # the non-blocking calls: every GPU's part is in flight at once, the frame is done when all are
+        big[:] = -3.0
+        hit2 = np.full_like(want_hit, -7)
+        m.render_begin(ra.Params(**kw), out, hit2)
+        with pytest.raises(host.VrtError) as e:
+            m.render(ra.Params(**kw))
+        assert e.value.code == abi.VRT_ERR_STATE
+        deadline = time.time() + 60
+        while not m.render_poll():
+            assert time.time() < deadline
+        st = m.render_end()
+        assert_frame_matches_oracle(out, hit2, st.rays, oracle_frame)
+        assert np.array_equal(out, want, equal_nan=True) and np.array_equal(hit2, want_hit)
+        assert st.pixels == cam.width * cam.height and st.gpu_ms > 0
+        with pytest.raises(host.VrtError) as e:
+            m.render_end()
+        assert e.value.code == abi.VRT_ERR_STATE
+        m.host_free(big)
         # the calls that make no sense across GPUs say so
         with pytest.raises(host.VrtError) as e:
-            m.render_begin(ra.Params(**kw), got)
+            m.render_begin_parts(ra.Params(**kw), got, None, 2)
         assert e.value.code == abi.VRT_ERR_INVALID
         with pytest.raises(host.VrtError):
             m.render(ra.Params(tile_index=0, tile_count=2, **kw))
@@ -104,7 +152,7 @@ def test_failed_scene_upload_keeps_the_old_scene(vrt_ctx, vrt_opts):
 
 
 @pytest.mark.parametrize("n_parts", [1, 3, 7])
-def test_frame_delivered_in_parts(vrt_ctx, n_parts):
+def test_frame_delivered_in_parts(vrt_ctx, oracle_mod, n_parts):
     """vrt_render_begin_parts delivers the frame strip set by strip set; a part's rows are final
     once vrt_render_poll_parts counts it, the other rows of the caller's buffer are untouched
     until their part lands, and the statistics are those of the whole frame."""
@@ -128,6 +176,7 @@ def test_frame_delivered_in_parts(vrt_ctx, n_parts):
             seen = done
         assert vrt_ctx.render_poll()
         st = vrt_ctx.render_end()
+        assert_frame_matches_oracle(rgba, hit, st.rays, _oracle_frame(oracle_mod, "parts", scene, cam, kw))
         assert np.array_equal(rgba, ref, equal_nan=True) and np.array_equal(hit, ref_hit)
         assert list(st.rays) == list(ref_st.rays) and st.pixels == cam.width * cam.height
         with pytest.raises(host.VrtError) as e:

@@ -83,6 +83,24 @@ def test_c5_ten_thousand_spheres_8k_64spp(vrt_ctx, oracle_mod):
     prm, rgba, hit, st = _properties(vrt_ctx, scene, cam, kw, offsets=offs)
     _sample_check(oracle_mod, scene, cam, prm, rgba, hit, n=400)
     assert sum(st.rays[1:]) > 4_000_000_000
+    # the same frame with the ray trees of 64 random pixels recorded (the consumer is the polyline of
+    # Assets/Scripts/RayTracer/RayTracerUnity.cs:620-654): 64 samples per pixel, segments in
+    # (sample, cast) order, the first 256 of each pixel kept and all of them counted
+    rng = np.random.default_rng(8)
+    px = rng.integers(0, cam.width * cam.height, 64).astype(np.int32)
+    rec = ra.Params(offsets=offs, **kw)
+    segs, counts = rec.record(px, cap=256)
+    rgba_r, hit_r, st_r = vrt_ctx.render(rec)
+    assert np.array_equal(rgba_r, rgba, equal_nan=True) and np.array_equal(hit_r, hit)
+    assert counts.sum() > 0
+    for i, pix in enumerate(px):
+        h, v = divmod(int(pix), cam.width)
+        _, _, o_segs, o_n, _ = oracle_mod.trace_pixel(scene, cam, ra.Params(offsets=offs, **kw).c, h, v, -1, 256)
+        assert counts[i] == o_n
+        for j in range(min(o_n, 256)):
+            a, b = segs[i * 256 + j], o_segs[j]
+            assert (a.kind, a.depth, a.hit_prim, a.sample) == (b.kind, b.depth, b.hit_prim, b.sample)
+            assert list(a.origin) == list(b.origin) and list(a.end) == list(b.end)
 
 
 def test_c4_million_triangles_1080p(vrt_ctx, oracle_mod):

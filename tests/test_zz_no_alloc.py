@@ -75,3 +75,49 @@ def test_noalloc_rejects_what_does_not_fit(vrt_ctx):
     ok = np.zeros((abi.VRT_NOALLOC_MAX_OFFSETS // 256, 256, 2), np.float32)
     vrt_ctx.render_device_noalloc(ra.Params(spp=256, offsets=ok, max_depth=1), buf.data_ptr())
     torch.cuda.synchronize()
+
+
+def test_noalloc_leaves_device_memory_alone_and_can_be_captured(vrt_ctx):
+    """What the entry point is named for: a call on a layout large enough for the tile-order
+    machinery of the other entry points (32 768 tiles), with a sampler table the GPU has not seen,
+    changes nothing in the device's free memory.  Then the use it is documented for: with the table
+    in place, the same call under stream capture becomes a graph whose replay renders the frame
+    (a new table under capture is refused, not silently uploaded)."""
+    import torch
+    vrt_ctx.set_scene(ra.random_spheres_scene(400, seed=4))
+    W, H = 1024, 512
+    vrt_ctx.set_camera(ra.random_spheres_camera(W, H))
+    rgba = torch.zeros((H, W, 4), device="cuda")
+    hit = torch.zeros((H, W), dtype=torch.int32, device="cuda")
+    side = torch.cuda.Stream()
+    tables = [host.sampler_table(abi.VRT_SAMPLER_JITTERED, 4, 5, 0.01, 0.01, seed=s) for s in (101, 102, 103)]
+    prm = [ra.Params(spp=4, offsets=t, seed=5, max_depth=4, rng=200.0) for t in tables]
+    vrt_ctx.render_device_noalloc(prm[0], rgba.data_ptr(), hit.data_ptr(), side.cuda_stream)   # warm: code objects, streams
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for k in (1, 2, 1):
+        vrt_ctx.render_device_noalloc(prm[k], rgba.data_ptr(), hit.data_ptr(), side.cuda_stream)
+        torch.cuda.synchronize()
+        assert torch.cuda.mem_get_info()[0] == free0, "vrt_render_device_noalloc changed the device's free memory"
+    want, want_hit, want_rays = rgba.cpu().numpy(), hit.cpu().numpy(), list(vrt_ctx.fetch_stats().rays)
+    ref = torch.zeros_like(rgba)
+    vrt_ctx.render_device(prm[1], ref.data_ptr(), None, side.cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(ref.cpu().numpy(), want, equal_nan=True)
+    # under capture: the table of the last call is in place
+    graph = torch.cuda.CUDAGraph()
+    rgba.zero_(); hit.fill_(-9)
+    torch.cuda.synchronize()
+    with torch.cuda.graph(graph, stream=side):
+        vrt_ctx.render_device_noalloc(prm[1], rgba.data_ptr(), hit.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        with pytest.raises(host.VrtError) as e:   # a table the array does not hold cannot be uploaded here
+            vrt_ctx.render_device_noalloc(prm[0], rgba.data_ptr(), hit.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        assert e.value.code == abi.VRT_ERR_STATE
+    torch.cuda.synchronize()
+    assert (hit.cpu().numpy() == -9).all()   # captured, not run
+    for _ in range(2):
+        rgba.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(rgba.cpu().numpy(), want, equal_nan=True) and np.array_equal(hit.cpu().numpy(), want_hit)
+        assert list(vrt_ctx.fetch_stats().rays) == want_rays

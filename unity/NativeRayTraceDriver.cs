@@ -29,7 +29,8 @@ public sealed class NativeRayTraceDriver : MonoBehaviour
     public void Init(Vector3 rayOrigin, ViewPortPlaneInformation viewPort, TextureInformation texture)
     {
         if (VrtNative.vrt_abi_version() != VrtNative.AbiVersion) throw new InvalidOperationException("libvrt: ABI version mismatch");
-        // Gpus > 1: the same calls on a context that spans GPUs 0 .. Gpus-1 of the node (blocking vrt_render only)
+        // Gpus > 1: the same calls on a context that spans GPUs 0 .. Gpus-1 of the node (frames in strip sets
+        // are a one-GPU call: StartFrameInParts falls back to StartFrame there)
         if (Gpus > 1) VrtNative.Check(IntPtr.Zero, VrtNative.vrt_create_multi(Gpus, null, out _ctx), "vrt_create_multi");
         else VrtNative.Check(IntPtr.Zero, VrtNative.vrt_create(0, out _ctx), "vrt_create");
         RebuildScene();
@@ -75,6 +76,7 @@ public sealed class NativeRayTraceDriver : MonoBehaviour
     public void StartFrameInParts(int nParts)
     {
         if (_frameInFlight) return;
+        if (Gpus > 1) { StartFrame(); return; }                          // PollParts then reports 0 until PollFrame says done
         VrtNative.Check(_ctx, VrtNative.vrt_render_begin_parts(_ctx, ref _prm, _pixelsPin.AddrOfPinnedObject(), _idsPin.AddrOfPinnedObject(), nParts),
                         "vrt_render_begin_parts");
         _frameInFlight = true; PartsInFlight = nParts;
