@@ -93,14 +93,28 @@ def algorithmic_flops(scene, rays, pixels):
     return queries * per_query + shaded * (25 + 30 * len(scene.lights)) + pixels * 12 + shaded * 8
 
 
-def profiled_counters(workload, prefix="r02"):
+# Clocks (of the nominal 2.4 GHz) a SIMD needs per wave64 vector instruction: the hardware model's
+# figure, and what tools/exp/valu_issue.hip sustained on an MI355X with 2-8 waves per SIMD
+# (profiles/r03/valu_issue_probe.txt: 2.34-2.94 depending on the instruction mix).
+VALU_CLOCKS_MODEL = 2.0
+VALU_CLOCKS_MEASURED = 2.45
+
+
+def profiled_counters(workload, prefix="r03"):
     """Issue-side view of the dominant kernel from the rocprofv3 summaries committed under
-    profiles/ (not measured live): share of the chip's vector-ALU issue slots the kernel used
-    (one wave64 instruction occupies a SIMD for 4 cycles; 1024 SIMDs at 2.4 GHz) and the mean
-    fraction of the 64 lanes active per vector instruction."""
+    profiles/ (not measured live): share of the chip's vector-ALU issue rate the kernel used and the
+    mean fraction of the 64 lanes active per vector instruction.  The issue rate is a measured one
+    (tools/exp/valu_issue.hip, profiles/r03/valu_issue_probe.txt): with two or more waves per SIMD a
+    SIMD issues one wave64 v_fma_f32 per 2.6-2.9 clocks of the nominal 2.4 GHz (2.3-2.5 for a mix of
+    FP and integer instructions; one wave alone: 5.9; v_pk_fma_f32: 4.4), i.e. the 2 clocks per
+    instruction of a SIMD-32 at the clock the chip holds under that load.  `valu_issue_frac` prices
+    an instruction at the 2 clocks of the hardware model, `valu_issue_frac_of_measured_peak` at the
+    2.45 clocks the probe sustained."""
     import csv
-    if not os.path.exists(os.path.join(ROOT, "profiles", f"{prefix}_{workload}_pmc.csv")):
-        prefix = "r01"
+    for older in ("r02", "r01"):
+        if os.path.exists(os.path.join(ROOT, "profiles", f"{prefix}_{workload}_pmc.csv")):
+            break
+        prefix = older
     try:
         pmc = {r["counter"]: float(r["mean_per_dispatch"])
                for r in csv.DictReader(open(os.path.join(ROOT, "profiles", f"{prefix}_{workload}_pmc.csv")))}
@@ -110,7 +124,8 @@ def profiled_counters(workload, prefix="r02"):
         return {"source": f"profiles/{prefix}_{workload}_pmc.csv, profiles/{prefix}_{workload}_kernel_stats.csv",
                 "kernel_avg_us": avg_ns / 1e3,
                 "valu_instructions_per_launch": insts,
-                "valu_issue_frac": insts * 4.0 / (1024 * 2.4e9 * avg_ns * 1e-9),
+                "valu_issue_frac": insts * VALU_CLOCKS_MODEL / (1024 * 2.4e9 * avg_ns * 1e-9),
+                "valu_issue_frac_of_measured_peak": insts * VALU_CLOCKS_MEASURED / (1024 * 2.4e9 * avg_ns * 1e-9),
                 "lane_utilisation": lanes / (insts * 64.0)}
     except Exception:
         return None
@@ -569,7 +584,9 @@ def main():
             roof["hbm_measured_GBps"] = roof["traffic"] / (kernel_ms * 1e-3) / 1e9
             roof["hbm_measured_frac"] = roof["hbm_measured_GBps"] / PEAK_HBM_GBPS
         out = {
-            "metric": "Mrays/s (primary+secondary) at 1080p depth 5",
+            # BASELINE.json's metric is quoted on the default workload; the other workloads name their own frame
+            "metric": "Mrays/s (primary+secondary) at 1080p depth 5" if args.workload == "c2"
+                      else f"Mrays/s (primary+secondary), {label}",
             "value": queries * args.steps / elapsed / 1e6,
             "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -609,12 +626,13 @@ def main():
             # the adapter gives PixelColorData) and, for reference, pageable numpy arrays.  Never `value`.
             hp = ra.Params(offsets=offsets, mode=mode, **kw)
 
-            def host_ms(rgba, hit, n):
-                ctx.render(hp, rgba=rgba, hit=hit, want_hit=hit is not None)
+            def host_ms(rgba, hit, n, prm=None):
+                prm = prm or hp
+                ctx.render(prm, rgba=rgba, hit=hit, want_hit=hit is not None)
                 ts = []
                 for _ in range(n):
                     t0 = time.perf_counter()
-                    ctx.render(hp, rgba=rgba, hit=hit, want_hit=hit is not None)
+                    ctx.render(prm, rgba=rgba, hit=hit, want_hit=hit is not None)
                     ts.append((time.perf_counter() - t0) * 1e3)
                 return float(np.median(ts))
 
@@ -622,6 +640,13 @@ def main():
             p_rgba, p_hit = ctx.host_alloc((H, W, 4), np.float32), ctx.host_alloc((H, W), np.int32)
             out["ms_per_frame_host"] = host_ms(p_rgba, p_hit, n_host)
             out["ms_per_frame_host_no_hit_ids"] = host_ms(p_rgba, None, n_host)
+            # the frame as the Color32 per pixel the player's RGBA32 texture holds anyway (VRT_OUT_RGBA8)
+            hp8 = ra.Params(offsets=offsets, mode=mode, **dict(kw, flags=kw.get("flags", 0) | abi.VRT_OUT_RGBA8))
+            p_rgba8 = ctx.host_alloc((H, W, 4), np.uint8)
+            rgba8_ms = host_ms(p_rgba8, None, n_host, hp8)
+            rgba8_ids_ms = host_ms(p_rgba8, p_hit, n_host, hp8)
+            rgba8_pageable_ms = host_ms(np.zeros((H, W, 4), np.uint8), None, min(n_host, 15), hp8)
+            ctx.host_free(p_rgba8)
             ctx.host_free(p_hit)
             ctx.host_free(p_rgba)
             h_rgba = np.zeros((H, W, 4), np.float32)
@@ -632,7 +657,11 @@ def main():
                 "ms_per_frame_page_locked": out["ms_per_frame_host"],
                 "ms_per_frame_page_locked_no_hit_ids": out["ms_per_frame_host_no_hit_ids"],
                 "ms_per_frame_pageable": pageable,
-                "Mrays_per_s_page_locked": queries / out["ms_per_frame_host"] / 1e3}
+                "Mrays_per_s_page_locked": queries / out["ms_per_frame_host"] / 1e3,
+                "rgba8": {"what": "the same call with VRT_OUT_RGBA8: 4 B/pixel, the Color32 of the player's RGBA32 texture",
+                          "ms_per_frame_page_locked_no_hit_ids": rgba8_ms, "ms_per_frame_page_locked": rgba8_ids_ms,
+                          "ms_per_frame_pageable_no_hit_ids": rgba8_pageable_ms,
+                          "Mrays_per_s_page_locked_no_hit_ids": queries / rgba8_ms / 1e3}}
         if world == 1 and args.emulate_ranks > 1:
             n = args.emulate_ranks
             per_rank, per_rank_rays = [], []

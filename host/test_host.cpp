@@ -76,6 +76,7 @@ static void gpu_checks()
     rt.planeYAxis = Vector3{0, 1, 0};
     rt.textureWidth = 96; rt.textureHeight = 64;
     rt.SampleSize = 4; rt.SampleSetCount = 5;
+    rt.WantHitIds = true;
     rt.Start();
     rt.RenderAll();
     std::vector<Color> frame = rt.PixelColorData();
@@ -143,6 +144,7 @@ static void dump_run(const std::string& dir)
     rt.textureWidth = 96; rt.textureHeight = 64;
     rt.SampleSize = 4; rt.SampleSetCount = 5;
     rt.SamplingMethod = AASamplingStrategy::Jittered;
+    rt.WantHitIds = true;
     rt.Start();
     rt.RenderAll();
     vrt_scene_desc d = w.Desc();

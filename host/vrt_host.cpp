@@ -159,7 +159,7 @@ void RayTracerUnity::Start()
 
 void RayTracerUnity::RenderAll()
 {
-    dev_.Check(vrt_render(dev_.ctx(), &params_, &pixels_[0].r, hitIds_.data(), &stats_));
+    dev_.Check(vrt_render(dev_.ctx(), &params_, &pixels_[0].r, WantHitIds ? hitIds_.data() : nullptr, &stats_));
 }
 
 void RayTracerUnity::SetTexturePixel(int x, int y, const Color& c)

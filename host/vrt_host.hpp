@@ -119,6 +119,9 @@ public:
     AASamplingStrategy SamplingMethod = AASamplingStrategy::Hammersley;
     int SampleSetCount = 83;
     bool VisualizePath = true;
+    // not in the reference: the primary hit ids of sample 0 are 4 more bytes per pixel over PCIe and
+    // nothing on the C# side consumes them, so RenderAll only fetches them when asked to
+    bool WantHitIds = false;
     // camera (:285, Info/ViewPortPlaneInformation.cs:86-99)
     Vector3 rayOrigin, planeP0, planeXAxis, planeYAxis;
     int textureWidth = 200, textureHeight = 200; // TextureDimension x TextureDimension in the C#

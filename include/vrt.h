@@ -75,7 +75,15 @@ enum {
        3 floats per pixel, the averaged radiance BEFORE MaxToOne (Util/RayTraceUtility.cs:409-422);
        vrt_tonemap_device turns it into the usual 4 floats.  Multi-GPU hosts gather strips in
        this form (12 instead of 16 bytes per pixel over xGMI) and tone-map once, after the gather. */
-    VRT_OUT_LINEAR_RGB = 1u << 8
+    VRT_OUT_LINEAR_RGB = 1u << 8,
+    /* Not a behaviour switch either: output format of every frame call (vrt_render, vrt_render_begin,
+       vrt_render_begin_parts, vrt_render_device).  The frame buffer receives 4 BYTES per pixel,
+       r, g, b, a, each channel round(255 * clamp01(c)) of the tone-mapped colour (halves to even,
+       NaN as 0): the Color32 a Texture2D of format RGBA32 holds after SetPixels + Apply
+       (RayTracerUnity.cs:472-475), which is all UpdateRenderTexture ever shows.  rgba_out then is
+       width*height*4 bytes, a quarter of what crosses PCIe per frame otherwise.  The float
+       Color[] stays the default and the format parity is stated on. */
+    VRT_OUT_RGBA8 = 1u << 9
 };
 
 /* Kernel organisation. */
@@ -310,7 +318,7 @@ int vrt_set_camera(vrt_ctx* ctx, const vrt_camera* cam);
 
 /* Whole frame: the loop Update → DoRayTraceArchitecture → UpdateScene over every pixel
  * (RayTracerUnity.cs:312-352,565-597,607-617).  rgba_out = width*height*4 floats
- * (PixelColorData layout, index h*width+v), hit_id_out = width*height int32 primary
+ * (PixelColorData layout, index h*width+v; width*height*4 bytes with VRT_OUT_RGBA8), hit_id_out = width*height int32 primary
  * primitive ids of sample 0 (may be NULL).  The buffers may be any host memory: a buffer of
  * vrt_host_alloc is written by the frame kernel itself, pageable memory (a pinned managed array)
  * is filled band by band from page-locked staging while the next band is traced. */

@@ -150,3 +150,12 @@ def trace_pixels(scene, cam, params, pixels):
                             C.c_void_p(px.ctypes.data), C.c_void_p(rgba.ctypes.data),
                             C.c_void_p(hit.ctypes.data), C.c_void_p(rays.ctypes.data))
     return rgba, hit, rays
+
+
+def rgba8(rgba):
+    """The Color32 an RGBA32 Texture2D holds after SetPixels(Color[]) + Apply
+    (Assets/Scripts/RayTracer/RayTracerUnity.cs:472-475; UnityEngine's Color -> Color32 conversion is
+    round(clamp01(c) * 255) per channel in float32, halves to even): the frame as the player shows it.
+    NaN channels (possible in the float frame, see the ambient occluder) become 0."""
+    x = np.nan_to_num(np.asarray(rgba, np.float32), nan=0.0, posinf=1.0, neginf=0.0)
+    return np.rint(np.clip(x, np.float32(0), np.float32(1)) * np.float32(255)).astype(np.uint8)

@@ -20,6 +20,7 @@ VRT_LIGHT_DIRECTIONAL, VRT_LIGHT_POINT = 0, 1
  VRT_SAMPLER_MULTIJITTERED, VRT_SAMPLER_HAMMERSLEY) = range(6)
 VRT_FIX_PRIMARY_SKY, VRT_FIX_AO_BASIS, VRT_FIX_DIELECTRIC = 1, 2, 4
 VRT_OUT_LINEAR_RGB = 1 << 8
+VRT_OUT_RGBA8 = 1 << 9
 VRT_MODE_AUTO, VRT_MODE_MEGAKERNEL, VRT_MODE_WAVEFRONT = 0, 1, 2
 (VRT_RAY_PRECHECK, VRT_RAY_PRIMARY, VRT_RAY_REFLECT, VRT_RAY_TRANSMIT, VRT_RAY_SHADOW,
  VRT_RAY_AO) = range(6)

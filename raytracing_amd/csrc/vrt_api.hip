@@ -657,6 +657,9 @@ extern "C" int vrt_set_camera(vrt_ctx* c, const vrt_camera* cam)
     return vrt_set_camera_one(c, cam);
 }
 
+// Bytes per pixel of the frame buffer a call writes: the Color of PixelColorData, or its Color32.
+static inline size_t frame_px_bytes(unsigned flags) { return (flags & VRT_OUT_RGBA8) ? 4 : sizeof(float4); }
+
 static int owned_rows(int H, int index, int count, int rows)
 {
     if (count <= 1) return H;
@@ -713,6 +716,7 @@ static int check_params(vrt_ctx* c, const vrt_params* p, DevParams* out)
     if (p->max_depth < 0 || p->max_depth > VRT_MAX_DEPTH) return fail(c, VRT_ERR_CAPACITY, "max_depth out of range");
     if (!(p->range > 0.f)) return fail(c, VRT_ERR_INVALID, "range must be positive");
     if (p->offsets && p->n_sets < 1) return fail(c, VRT_ERR_INVALID, "n_sets must be >= 1");
+    if ((p->flags & VRT_OUT_LINEAR_RGB) && (p->flags & VRT_OUT_RGBA8)) return fail(c, VRT_ERR_INVALID, "VRT_OUT_LINEAR_RGB and VRT_OUT_RGBA8 exclude each other");
     int tcount = p->tile_count > 1 ? p->tile_count : 1;
     if (tcount > 1 && (p->tile_index < 0 || p->tile_index >= tcount || p->tile_rows < 1))
         return fail(c, VRT_ERR_INVALID, "bad tile parameters");
@@ -1053,11 +1057,12 @@ static int copy_rows_out(vrt_ctx* c, const DevParams& P, float* rgba_out, int32_
 {
     const size_t W = (size_t)c->cam.width;
     const int H = c->cam.height;
+    const size_t pxb = frame_px_bytes(P.flags);
     if (P.tile_count <= 1 || P.compact) {
         const size_t nout = P.compact ? (size_t)P.local_rows * W : W * H;
         if (nout == 0) return VRT_OK;
         if (rgba_out)   // null: the frame kernel has written the caller's buffer itself
-            HIPCHK(c, hipMemcpyAsync(rgba_out, c->d_rgba, nout * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(rgba_out, c->d_rgba, nout * pxb, hipMemcpyDeviceToHost, c->stream));
         if (hit_id_out)
             HIPCHK(c, hipMemcpyAsync(hit_id_out, c->d_hit, nout * sizeof(int), hipMemcpyDeviceToHost, c->stream));
         return VRT_OK;
@@ -1079,7 +1084,7 @@ static int copy_rows_out(vrt_ctx* c, const DevParams& P, float* rgba_out, int32_
                                   (size_t)tail_rows * W * px_bytes, hipMemcpyDeviceToHost, c->stream);
         return hipSuccess;
     };
-    if (rgba_out) HIPCHK(c, strided(rgba_out, c->d_rgba, sizeof(float4)));
+    if (rgba_out) HIPCHK(c, strided(rgba_out, c->d_rgba, pxb));
     if (hit_id_out) HIPCHK(c, strided(hit_id_out, c->d_hit, sizeof(int)));
     return VRT_OK;
 }
@@ -1121,7 +1126,10 @@ static int begin_frame(vrt_ctx* c, const vrt_params* p, float* rgba_out, int32_t
     // in vrt_stats then includes the transfer).  Hit ids, 32 bytes per row segment, are slower that
     // way than in one copy and keep going through the device buffer.
     const size_t rows_out = P.compact ? (size_t)P.local_rows : (size_t)c->cam.height;
-    float4* direct = c->opt.zero_copy ? (float4*)device_view_of_host_alloc(c, rgba_out, rows_out * c->cam.width * sizeof(float4)) : nullptr;
+    // (Not the 4-byte Color32 format: a wave's tile is 8 pixels wide at one sample per pixel, 32-byte
+    // row segments cross PCIe worse than one copy after the kernel, 0.357 against 0.322 ms at 1080p.)
+    const bool store_direct = c->opt.zero_copy && !(P.flags & VRT_OUT_RGBA8);
+    float4* direct = store_direct ? (float4*)device_view_of_host_alloc(c, rgba_out, rows_out * c->cam.width * frame_px_bytes(P.flags)) : nullptr;
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     rc = enqueue_frame(c, p, P, direct ? direct : c->d_rgba, hit_id_out ? c->d_hit : nullptr, c->stream);
     if (rc) return rc;
@@ -1142,7 +1150,7 @@ static int begin_frame(vrt_ctx* c, const vrt_params* p, float* rgba_out, int32_t
 static int render_staged(vrt_ctx* c, const vrt_params* p, float* rgba_out, int32_t* hit_id_out, vrt_stats* stats_out)
 {
     if (!c->opt.staged || !c->have_cam || p->tile_count > 1 || p->compact_rows || (p->flags & VRT_OUT_LINEAR_RGB)) return 1;
-    const size_t W = (size_t)c->cam.width, H = (size_t)c->cam.height, px = W * H;
+    const size_t W = (size_t)c->cam.width, H = (size_t)c->cam.height, px = W * H, pxb = frame_px_bytes(p->flags);
     if (px < (size_t)1 << 18) return 1;   // small frames: the bands' launches would cost more than they hide
     HIPCHK(c, hipSetDevice(c->device));
     hipPointerAttribute_t at;
@@ -1181,7 +1189,7 @@ static int render_staged(vrt_ctx* c, const vrt_params* p, float* rgba_out, int32
             if (e != hipSuccess) { err[me] = e; return; }
             const size_t b0 = (size_t)k * band, b1 = b0 + band < H ? b0 + band : H;
             const size_t r0 = b0 + (b1 - b0) * me / n_thr, r1 = b0 + (b1 - b0) * (me + 1) / n_thr;
-            memcpy(rgba_out + r0 * W * 4, c->stage_rgba + r0 * W * 4, (r1 - r0) * W * sizeof(float4));
+            memcpy((char*)rgba_out + r0 * W * pxb, (const char*)c->stage_rgba + r0 * W * pxb, (r1 - r0) * W * pxb);
             if (hit_id_out) memcpy(hit_id_out + r0 * W, c->stage_hit + r0 * W, (r1 - r0) * W * sizeof(int32_t));
         }
     };
@@ -1280,7 +1288,8 @@ extern "C" int vrt_render_begin_parts(vrt_ctx* c, const vrt_params* p, float* rg
     HIPCHK(c, hipMemsetAsync(c->d_ctr, 0, kCtrBlock * sizeof(unsigned long long), c->stream));
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     // as in begin_frame: a buffer of vrt_host_alloc is written by the kernels themselves
-    float4* direct = c->opt.zero_copy ? (float4*)device_view_of_host_alloc(c, rgba_out, (size_t)c->cam.height * c->cam.width * sizeof(float4)) : nullptr;
+    const bool store_direct = c->opt.zero_copy && !(p->flags & VRT_OUT_RGBA8);
+    float4* direct = store_direct ? (float4*)device_view_of_host_alloc(c, rgba_out, (size_t)c->cam.height * c->cam.width * frame_px_bytes(p->flags)) : nullptr;
     uint64_t pixels = 0;
     for (int k = 0; k < n_parts; ++k) {
         q.tile_index = k;

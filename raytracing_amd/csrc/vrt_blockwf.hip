@@ -166,12 +166,7 @@ __global__ __launch_bounds__(256, 4) void k_mega_blk(DevScene S, DevCam cam, Dev
     if (inside && si == 0) {
         f3 fin = sum / (float)P.spp;
         size_t idx = (size_t)(P.compact ? r : h) * cam.width + v; // RayTracerUnity.cs:442
-        if (P.flags & VRT_OUT_LINEAR_RGB) {
-            float* o = (float*)rgba + 3 * idx;
-            o[0] = fin.x; o[1] = fin.y; o[2] = fin.z;
-        } else {
-            rgba[idx] = process_color(fin);
-        }
+        store_pixel(P, rgba, idx, fin);
         if (hit_id) hit_id[idx] = id;
     }
     flush_counters(C, ctr, blockIdx.x);

@@ -140,12 +140,7 @@ __global__ __launch_bounds__(VRT_MEGA_THREADS, BVH ? VRT_BVH_WAVES : (SIMPLE ? V
         // x / 1 is x: one sample per pixel needs no IEEE divisions (a wave-uniform branch)
         f3 fin = P.spp == 1 ? sum : sum / (float)P.spp;
         size_t idx = (size_t)(P.compact ? r : h) * cam.width + v; // RayTracerUnity.cs:442
-        if (P.flags & VRT_OUT_LINEAR_RGB) {   // 3 floats per pixel, tone mapping left to vrt_tonemap_device
-            float* o = (float*)rgba + 3 * idx;
-            o[0] = fin.x; o[1] = fin.y; o[2] = fin.z;
-        } else {
-            rgba[idx] = process_color(fin);
-        }
+        store_pixel(P, rgba, idx, fin);
         if (hit_id) hit_id[idx] = id;
     }
     flush_counters(C, ctr, blockIdx.x);

@@ -120,15 +120,18 @@ struct StripLayout {
 };
 
 // Frame row h, column v from the gathered strips: radiance -> process_color, and the hit id.
-__global__ __launch_bounds__(256) void k_assemble(StripLayout L, const float* __restrict__ rgb, const int* __restrict__ hits,
-                                                  float4* __restrict__ rgba_out, int* __restrict__ hit_out)
+__global__ __launch_bounds__(256) void k_assemble(StripLayout L, unsigned out_flags, const float* __restrict__ rgb,
+                                                  const int* __restrict__ hits, float4* __restrict__ rgba_out,
+                                                  int* __restrict__ hit_out)
 {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (size_t)L.width * L.height) return;
     const int h = (int)(i / L.width), v = (int)(i % L.width);
     const int s = h / L.rows, k = s % L.n;
     const size_t src = L.first_px[k] + ((size_t)(s / L.n) * L.rows + (h % L.rows)) * L.width + v;
-    rgba_out[i] = process_color(mk3(rgb[3 * src], rgb[3 * src + 1], rgb[3 * src + 2]));
+    DevParams P;
+    P.flags = out_flags;   // the frame's own format: Color, or Color32 with VRT_OUT_RGBA8
+    store_pixel(P, rgba_out, i, mk3(rgb[3 * src], rgb[3 * src + 1], rgb[3 * src + 2]));
     if (hit_out) hit_out[i] = hits[src];
 }
 
@@ -432,7 +435,7 @@ static int multi_render_gather(vrt_ctx* c, const vrt_params* p, float* rgba_out,
         }
         vrt_params q = *p;
         q.tile_index = k; q.tile_count = n; q.tile_rows = rows; q.compact_rows = 1;
-        q.flags |= VRT_OUT_LINEAR_RGB;
+        q.flags = (q.flags & ~(unsigned)VRT_OUT_RGBA8) | VRT_OUT_LINEAR_RGB;   // strips travel as radiance; the frame's format is applied after the gather
         q.n_record_pixels = 0;
         int r = vrt_render_device_one(s, &q, rgb, want_hits ? hit : nullptr, s->stream);
         if (r != VRT_OK) return r;
@@ -471,11 +474,11 @@ static int multi_render_gather(vrt_ctx* c, const vrt_params* p, float* rgba_out,
 
     // rows back in frame order, tone mapping, read-back
     const size_t npix = (size_t)W * H;
-    hipLaunchKernelGGL(k_assemble, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, c->stream, L, m->d_gather,
+    hipLaunchKernelGGL(k_assemble, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, c->stream, L, p->flags & VRT_OUT_RGBA8, m->d_gather,
                        want_hits ? m->d_gather_hit : nullptr, c->d_rgba, want_hits ? c->d_hit : nullptr);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));
-    HIPCHK(c, hipMemcpyAsync(rgba_out, c->d_rgba, npix * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(rgba_out, c->d_rgba, npix * ((p->flags & VRT_OUT_RGBA8) ? 4 : sizeof(float4)), hipMemcpyDeviceToHost, c->stream));
     if (want_hits) HIPCHK(c, hipMemcpyAsync(hit_id_out, c->d_hit, npix * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (int k = 1; k < n; ++k) {   // senders are done when the receiver is; make their streams say so too

@@ -1645,6 +1645,28 @@ __device__ __forceinline__ float4 process_color(f3 c)
     return make_float4(c.x, c.y, c.z, 1.f);
 }
 
+// One channel as a Color32 holds it: round(255 * clamp01(c)), halves to even, NaN as 0.
+__device__ __forceinline__ unsigned channel8(float c)
+{
+    return (unsigned)__builtin_rintf(fminf(fmaxf(c, 0.f), 1.f) * 255.f);   // fmaxf drops a NaN
+}
+
+// Stores the averaged radiance `fin` of pixel idx in the format the call asked for: the tone-mapped
+// Color (4 floats), its Color32 (4 bytes, VRT_OUT_RGBA8), or the radiance itself (3 floats,
+// VRT_OUT_LINEAR_RGB, tone mapping left to vrt_tonemap_device).
+__device__ __forceinline__ void store_pixel(const DevParams& P, float4* rgba, size_t idx, f3 fin)
+{
+    if (P.flags & VRT_OUT_LINEAR_RGB) {
+        float* o = (float*)rgba + 3 * idx;
+        o[0] = fin.x; o[1] = fin.y; o[2] = fin.z;
+    } else if (P.flags & VRT_OUT_RGBA8) {
+        const float4 c = process_color(fin);
+        ((unsigned*)rgba)[idx] = channel8(c.x) | (channel8(c.y) << 8) | (channel8(c.z) << 16) | (channel8(c.w) << 24);
+    } else {
+        rgba[idx] = process_color(fin);
+    }
+}
+
 struct PendingRay { f3 o, d, T; int depth, skip, kind; };
 
 // Tracer/WhittedTracer.cs:33-104 as an iterative loop: radiance is accumulated as

@@ -533,12 +533,7 @@ __global__ __launch_bounds__(256) void k_wf_resolve(DevCam cam, DevParams P, WfW
     if (live && si == 0) {
         f3 fin = sum / (float)P.spp;
         const size_t idx = (size_t)(P.compact ? r : h) * cam.width + v;
-        if (P.flags & VRT_OUT_LINEAR_RGB) {
-            float* o = (float*)rgba + 3 * idx;
-            o[0] = fin.x; o[1] = fin.y; o[2] = fin.z;
-        } else {
-            rgba[idx] = process_color(fin);
-        }
+        store_pixel(P, rgba, idx, fin);
     }
 }
 

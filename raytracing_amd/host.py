@@ -184,8 +184,8 @@ class Context:
     def render(self, params, rgba=None, hit=None, want_hit=True):
         """Whole frame into host arrays. Returns (rgba[H,W,4], hit[H,W] or None, vrt_stats)."""
         H, W = self.cam.height, self.cam.width
-        if rgba is None:
-            rgba = np.zeros((H, W, 4), np.float32)
+        if rgba is None:   # VRT_OUT_RGBA8: a Color32 per pixel instead of a Color
+            rgba = np.zeros((H, W, 4), np.uint8 if params.c.flags & abi.VRT_OUT_RGBA8 else np.float32)
         if hit is None and want_hit:
             hit = np.full((H, W), -1, np.int32)
         st = abi.vrt_stats()

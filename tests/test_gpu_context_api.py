@@ -356,3 +356,70 @@ def test_frames_into_pageable_memory_go_through_staging(vrt_ctx, oracle_mod):
     assert np.array_equal(a[4], b[4]) and a[5] == b[5]
     o_rgba, o_hit, o_rays = oracle_mod.render(scene, cam, ra.Params(**kw).c, n_threads=8)
     assert np.array_equal(a[1], o_hit) and np.array_equal(np.array(a[2], np.uint64), o_rays)
+
+
+@pytest.mark.parametrize("which", ["teaching", "spheres"])
+def test_frames_as_color32(vrt_ctx, oracle_mod, which):
+    """VRT_OUT_RGBA8: the frame as the RGBA32 texture of the player holds it after SetPixels + Apply
+    (Assets/Scripts/RayTracer/RayTracerUnity.cs:472-475), 4 bytes per pixel.  Every way a frame
+    reaches the caller (pageable memory, page-locked memory written by the kernel, staged bands,
+    strip sets, non-blocking, device memory, both kernel organisations, several GPUs) must deliver
+    the quantisation of its own float frame bit for bit, and stay within one step of the
+    quantised oracle frame (the float frames differ by up to 1/255)."""
+    import torch
+    if which == "teaching":
+        scene, cam, kw = ra.teaching_scene(), ra.teaching_camera(640, 411), dict(spp=1, max_depth=5)   # 2^18 pixels: staged bands
+    else:
+        scene, cam, kw = _spheres()
+    vrt_ctx.set_scene(scene)
+    vrt_ctx.set_camera(cam)
+    H, W = cam.height, cam.width
+    f32, hit, st = vrt_ctx.render(ra.Params(**kw))
+    want = oracle_mod.rgba8(f32)
+    kw8 = dict(kw, flags=abi.VRT_OUT_RGBA8)
+    got, got_hit, st8 = vrt_ctx.render(ra.Params(**kw8))
+    assert got.dtype == np.uint8 and np.array_equal(got, want) and np.array_equal(got_hit, hit)
+    assert list(st8.rays) == list(st.rays)
+    if which == "spheres":
+        o = oracle_mod.rgba8(_oracle_frame(oracle_mod, "rgba8", scene, cam, kw)[0])
+        assert np.abs(got.astype(np.int32) - o.astype(np.int32)).max() <= 1
+    # page-locked buffer inside a larger allocation: written by the kernel, nothing beside it touched
+    big = vrt_ctx.host_alloc((H + 4, W, 4), np.uint8)
+    try:
+        big[:] = 7
+        out = big[2:2 + H]
+        vrt_ctx.render(ra.Params(**kw8), rgba=out, want_hit=False)
+        assert np.array_equal(out, want) and (big[:2] == 7).all() and (big[2 + H:] == 7).all()
+        # strip sets, non-blocking
+        big[:] = 7
+        vrt_ctx.render_begin_parts(ra.Params(tile_rows=8, **kw8), out, None, 3)
+        vrt_ctx.render_end()
+        assert np.array_equal(out, want)
+    finally:
+        vrt_ctx.host_free(big)
+    page = np.full((H, W, 4), 7, np.uint8)
+    vrt_ctx.render_begin(ra.Params(tile_index=1, tile_count=2, tile_rows=8, **kw8), page)
+    vrt_ctx.render_end()
+    mine = np.array([(h // 8) % 2 == 1 for h in range(H)])
+    assert np.array_equal(page[mine], want[mine]) and (page[~mine] == 7).all()
+    # wavefront organisation, device memory
+    wf, _, _ = vrt_ctx.render(ra.Params(mode=abi.VRT_MODE_WAVEFRONT, **kw8))
+    assert np.array_equal(wf, want)
+    dev = torch.zeros((H, W), dtype=torch.int32, device="cuda")
+    vrt_ctx.render_device(ra.Params(**kw8), dev.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(dev.cpu().numpy().view(np.uint8).reshape(H, W, 4), want)
+    # several GPUs, delivered per GPU and gathered
+    m = host.Context(devices=[0, 0])
+    try:
+        m.set_scene(scene)
+        m.set_camera(cam)
+        for gather in (0, 1):
+            m.set_option("multi_gather", gather)
+            g8, g_hit, _ = m.render(ra.Params(**kw8))
+            assert np.array_equal(g8, want) and np.array_equal(g_hit, hit)
+    finally:
+        m.close()
+    with pytest.raises(host.VrtError) as e:
+        vrt_ctx.render(ra.Params(**dict(kw, flags=abi.VRT_OUT_RGBA8 | abi.VRT_OUT_LINEAR_RGB)))
+    assert e.value.code == abi.VRT_ERR_INVALID

@@ -16,6 +16,9 @@ public sealed class NativeRayTraceDriver : MonoBehaviour
     public int SampleSetCount = 83;
     public uint Seed = 1;
     public int Gpus = 1;
+    public bool WantHitIds = false;   // primary hit ids of sample 0: 4 more bytes per pixel over PCIe, only fetched when asked for
+    public bool Rgba8 = false;        // frames as Color32 (VRT_OUT_RGBA8): what the RGBA32 texture holds after SetPixels anyway (:472-475)
+    public Color32[] Pixels32;        // with Rgba8: the frame, for Texture2D.SetPixels32 / LoadRawTextureData
 
     IntPtr _ctx = IntPtr.Zero;
     VrtNative.Params _prm;
@@ -46,9 +49,9 @@ public sealed class NativeRayTraceDriver : MonoBehaviour
         VrtNative.vrt_params_defaults(out _prm);
         _prm.spp = SampleSize; _prm.nSets = SampleSetCount; _prm.offsets = _offsetsPin.AddrOfPinnedObject(); _prm.seed = Seed;
         _prm.maxDepth = RayTraceUtility.GlobalWorld.MaxDepth; _prm.range = RayTraceRange;
-        _hitIds = new int[dim * dim];
-        _pixelsPin = GCHandle.Alloc(texture.PixelColorData, GCHandleType.Pinned);
-        _idsPin = GCHandle.Alloc(_hitIds, GCHandleType.Pinned);
+        if (Rgba8) { Pixels32 = new Color32[dim * dim]; _prm.flags |= VrtNative.OutRgba8; }
+        _pixelsPin = GCHandle.Alloc(Rgba8 ? (object)Pixels32 : texture.PixelColorData, GCHandleType.Pinned);
+        if (WantHitIds) { _hitIds = new int[dim * dim]; _idsPin = GCHandle.Alloc(_hitIds, GCHandleType.Pinned); }
         Tracer = new NativeTracer(_ctx, _prm);
         RayTraceUtility.GlobalWorld.Tracer = Tracer;                      // replaces :300-304
     }
@@ -61,11 +64,13 @@ public sealed class NativeRayTraceDriver : MonoBehaviour
         _scene.Upload(_ctx);
     }
 
+    IntPtr IdsPtr() { return WantHitIds ? _idsPin.AddrOfPinnedObject() : IntPtr.Zero; }
+
     /// Continuous mode: starts the frame; Update polls it.
     public void StartFrame()
     {
         if (_frameInFlight) return;
-        VrtNative.Check(_ctx, VrtNative.vrt_render_begin(_ctx, ref _prm, _pixelsPin.AddrOfPinnedObject(), _idsPin.AddrOfPinnedObject()), "vrt_render_begin");
+        VrtNative.Check(_ctx, VrtNative.vrt_render_begin(_ctx, ref _prm, _pixelsPin.AddrOfPinnedObject(), IdsPtr()), "vrt_render_begin");
         _frameInFlight = true;
     }
 
@@ -77,7 +82,7 @@ public sealed class NativeRayTraceDriver : MonoBehaviour
     {
         if (_frameInFlight) return;
         if (Gpus > 1) { StartFrame(); return; }                          // PollParts then reports 0 until PollFrame says done
-        VrtNative.Check(_ctx, VrtNative.vrt_render_begin_parts(_ctx, ref _prm, _pixelsPin.AddrOfPinnedObject(), _idsPin.AddrOfPinnedObject(), nParts),
+        VrtNative.Check(_ctx, VrtNative.vrt_render_begin_parts(_ctx, ref _prm, _pixelsPin.AddrOfPinnedObject(), IdsPtr(), nParts),
                         "vrt_render_begin_parts");
         _frameInFlight = true; PartsInFlight = nParts;
     }

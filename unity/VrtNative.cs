@@ -21,6 +21,7 @@ public static class VrtNative
     public const int LightDirectional = 0, LightPoint = 1;
     public const uint FixPrimarySky = 1, FixAoBasis = 2, FixDielectric = 4;
     public const uint OutLinearRgb = 1u << 8;   // vrt_render_device only: 3 floats per pixel before MaxToOne
+    public const uint OutRgba8 = 1u << 9;       // every frame call: a Color32 per pixel, what the RGBA32 texture holds after SetPixels (RayTracerUnity.cs:472-475)
     public const int ModeAuto = 0, ModeMegakernel = 1, ModeWavefront = 2;
     public const int RayPrecheck = 0, RayPrimary = 1, RayReflect = 2, RayTransmit = 3, RayShadow = 4, RayAo = 5;
 
