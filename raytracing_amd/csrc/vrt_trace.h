@@ -144,6 +144,57 @@ __device__ __forceinline__ bool hit_aab(f3 p, f3 d, f3 inv, float h0, float h1, 
     return true;
 }
 
+// hit_aab in two parts for the brute-force loop, which needs the entry distance of every box it tests
+// but the entry face only of the one box that ends up as the closest hit (and never for an
+// occlusion query).  aab_slabs: the same slabs, same operations, without the face; it accepts
+// exactly the rays hit_aab accepts (an axis updates tn in hit_aab iff nr > tn here, or on a tie,
+// which leaves tn as it is; a ray for which no axis ever updates tn ends with tn = -inf and is
+// rejected by tn >= 0 as hit_aab rejects it by its face staying unset).
+__device__ __forceinline__ bool aab_slabs(f3 p, f3 d, f3 inv, float h0, float h1, float h2, float maxd, float& t)
+{
+    bool inside = (fabsf(p.x) <= h0) && (fabsf(p.y) <= h1) && (fabsf(p.z) <= h2);
+    if (inside) return false;
+    float tn = -INFINITY, tf = INFINITY;
+#define VRT_WSLAB(PJ, DJ, INV, H)                                                      \
+    if (DJ == 0.f) { if (fabsf(PJ) > H) return false; }                                \
+    else {                                                                             \
+        float t1 = (-H - PJ) * INV, t2 = (H - PJ) * INV;                               \
+        bool pos = DJ > 0.f;                                                           \
+        float nr = pos ? t1 : t2, fr = pos ? t2 : t1;                                  \
+        if (nr > tn) tn = nr;                                                          \
+        if (fr < tf) tf = fr;                                                          \
+    }
+    VRT_WSLAB(p.x, d.x, inv.x, h0)
+    VRT_WSLAB(p.y, d.y, inv.y, h1)
+    VRT_WSLAB(p.z, d.z, inv.z, h2)
+#undef VRT_WSLAB
+    if (!(tn <= tf)) return false;
+    if (!(tn >= 0.f && tn <= maxd)) return false;
+    t = tn;
+    return true;
+}
+
+// The face code hit_aab reports for a box the ray is known to hit: the axis of the largest entry
+// distance, the lowest local axis among equal ones.
+__device__ __forceinline__ int aab_face(f3 p, f3 d, f3 inv, float h0, float h1, float h2, int fl)
+{
+    float tn = -INFINITY;
+    int ax = 0, kb = -1;
+#define VRT_WFACE(J, PJ, DJ, INV, H)                                                   \
+    if (DJ != 0.f) {                                                                   \
+        const int kj = (fl >> (2 * J)) & 3;                                            \
+        const bool flip = ((fl >> (8 + J)) & 1) != 0;                                  \
+        const bool pos = DJ > 0.f;                                                     \
+        const float nr = (pos ? -H - PJ : H - PJ) * INV;                               \
+        if (nr > tn || (nr == tn && kj < kb)) { tn = nr; kb = kj; ax = kj | ((pos == flip) ? 4 : 0); } \
+    }
+    VRT_WFACE(0, p.x, d.x, inv.x, h0)
+    VRT_WFACE(1, p.y, d.y, inv.y, h1)
+    VRT_WFACE(2, p.z, d.z, inv.z, h2)
+#undef VRT_WFACE
+    return ax;
+}
+
 // Slab core of the box test on box-local coordinates: lo = origin, ld = direction, inv = 1/ld.
 // aux = axis | (entered through the +axis face ? 4 : 0)
 __device__ __forceinline__ bool box_slabs(float lo0, float lo1, float lo2, float ld0, float ld1, float ld2,
@@ -263,9 +314,17 @@ __device__ __forceinline__ Hit intersect_brute(const DevScene& S, f3 o, f3 d, fl
     Hit best; best.t = INFINITY; best.prim = -1; best.aux = 0;
     if (is_zero3(d)) return best;
     for (int i = 0; i < S.n_sph; ++i) {
-        float t;
-        bool h = CAM ? hit_sphere_pre(VRT_PRE(i), d, maxd, t) : hit_sphere(VRT_SPH(i), o, d, maxd, t);
-        if (i != skip && h && t < best.t && t < tlim) {
+        // hit_sphere / hit_sphere_pre in two steps: most spheres are missed by every ray of a wave
+        // (neighbouring pixels, or the occlusion rays of their hits), and the square root, which IEEE
+        // rounding makes 16 instructions, is only taken when some lane's ray passes the rejection test
+        float b, cc;
+        if (CAM) { const float4 pre = VRT_PRE(i); b = dot3(xyz(pre), d); cc = pre.w; }
+        else { const float4 sp = VRT_SPH(i); const f3 oc = o - xyz(sp); b = dot3(oc, d); cc = dot3(oc, oc) - sp.w * sp.w; }
+        const float disc = b * b - cc;
+        const bool pass = i != skip && cc > 0.f && b < 0.f && disc >= 0.f;
+        if (!__any(pass)) continue;
+        const float t = -b - sqrtf(disc);
+        if (pass && t >= 0.f && t <= maxd && t < best.t && t < tlim) {
             best.t = t; best.prim = i;
             if (ANY) return best;
         }
@@ -274,7 +333,7 @@ __device__ __forceinline__ Hit intersect_brute(const DevScene& S, f3 o, f3 d, fl
         // every box is aligned with the world axes: one reciprocal per ray component serves all
         const f3 inv = mk3(1.f / d.x, 1.f / d.y, 1.f / d.z);
         for (int i = 0; i < S.n_box; ++i) {
-            float t; int aux;
+            float t;
             const float4 a0 = VRT_AAB(2 * i), a1 = VRT_AAB(2 * i + 1);
             const f3 p = CAM ? xyz(VRT_PRE(S.n_sph + i)) : o - xyz(a0);
 #if VRT_AAB_CULL
@@ -283,11 +342,17 @@ __device__ __forceinline__ Hit intersect_brute(const DevScene& S, f3 o, f3 d, fl
             bool may = !((bb * bb - cs + slack < 0.f) || (cs > slack && bb > 0.f));
             if (!__any(may)) continue;
 #endif
-            if (i + S.n_sph != skip && hit_aab(p, d, inv, a1.x, a1.y, a1.z, __float_as_int(a0.w), maxd, t, aux) &&
-                t < best.t && t < tlim) {
-                best.t = t; best.prim = i + S.n_sph; best.aux = aux;
+            if (i + S.n_sph != skip && aab_slabs(p, d, inv, a1.x, a1.y, a1.z, maxd, t) && t < best.t && t < tlim) {
+                best.t = t; best.prim = i + S.n_sph;
                 if (ANY) return best;
             }
+        }
+        // the entry face of the closest box, once per query instead of once per box tested
+        if (!ANY && best.prim >= S.n_sph) {
+            const int bi = best.prim - S.n_sph;
+            const float4 a0 = S.aab[2 * bi], a1 = S.aab[2 * bi + 1];
+            const f3 p = CAM ? xyz(S.cam_pre[S.n_sph + bi]) : o - xyz(a0);
+            best.aux = aab_face(p, d, inv, a1.x, a1.y, a1.z, __float_as_int(a0.w));
         }
     } else {
         for (int i = 0; i < S.n_box; ++i) {
