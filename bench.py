@@ -684,15 +684,27 @@ def main():
                 "predicted_parallel_efficiency_render_only": kernel_ms / (n * max(per_rank)),
                 "note": "each rank's strips rendered alone on this GPU; excludes the RCCL gather"}
         if world == 1 and args.record > 0:
+            # Record mode (the consumer is the polyline of RayTracerUnity.cs:620-654): the same frame call
+            # with the ray trees of a bounded set of pixels recorded.  Timed against the same call without
+            # records, both into buffers that have been written before, so that the difference is the
+            # recording pass itself (kernel + copies of the segments), not first-touch page faults.
             rng = np.random.default_rng(0)
             px = rng.integers(0, W * H, args.record).astype(np.int32)
+            cap = 256
             rp = ra.Params(offsets=offsets, mode=mode, **kw)
-            segs, counts = rp.record(px, cap=64)
-            t0 = time.perf_counter()
-            ctx.render(rp, rgba=np.zeros((H, W, 4), np.float32), hit=np.zeros((H, W), np.int32))
-            out["record_mode"] = {"pixels": int(args.record), "cap": 64, "segments": int(counts.sum()),
-                                  "overflowed_pixels": int((counts > 64).sum()),
-                                  "frame_plus_records_ms": (time.perf_counter() - t0) * 1e3}
+            segs, counts = rp.record(px, cap=cap)
+            plain = ra.Params(offsets=offsets, mode=mode, **kw)
+            r_rgba, r_hit = ctx.host_alloc((H, W, 4), np.float32), ctx.host_alloc((H, W), np.int32)
+            ctx.render(rp, rgba=r_rgba, hit=r_hit)
+            t_plain, t_rec = [], []
+            for _ in range(3):
+                t0 = time.perf_counter(); ctx.render(plain, rgba=r_rgba, hit=r_hit); t_plain.append((time.perf_counter() - t0) * 1e3)
+                t0 = time.perf_counter(); ctx.render(rp, rgba=r_rgba, hit=r_hit); t_rec.append((time.perf_counter() - t0) * 1e3)
+            ctx.host_free(r_hit); ctx.host_free(r_rgba)
+            out["record_mode"] = {"pixels": int(args.record), "cap": cap, "segments": int(counts.sum()),
+                                  "overflowed_pixels": int((counts > cap).sum()),
+                                  "frame_ms": float(np.median(t_plain)), "frame_plus_records_ms": float(np.median(t_rec)),
+                                  "records_ms": float(np.median(t_rec) - np.median(t_plain))}
         if world > 1 and not rehearsal and not args.no_in_library_multi:
             # every rank is idle here (rank 0 is past the last barrier of the timed work and the others
             # wait in the barrier below), so the GPUs are free for the one-process form

@@ -155,13 +155,22 @@ __global__ __launch_bounds__(VRT_MEGA_THREADS, BVH ? VRT_BVH_WAVES : (SIMPLE ? V
 // defaults to the straight-line one, so every test run checks both against the oracle and
 // against each other (vrt_trace_pixel must reproduce the frame's pixel bit for bit).
 
+// One wave per listed pixel, one lane per anti-aliasing sample (rounds of 64 when there are more).
+// The segments of a pixel must come out in (sample, cast) order in one array of `cap` entries, and a
+// lane only knows where its sample's segments start once the samples before it have been counted:
+// every round is therefore traced twice, first counting (nothing stored), then, after a prefix sum
+// over the lanes in sample order, storing from each lane's own offset.  Twice the rays, but 64
+// samples at a time instead of one after the other.  Rays are counted once (second pass only), and
+// the pixel's colour is summed in sample order, so colour, hit id, counts and segments are those of
+// the serial loop bit for bit.
 template <bool BVH, bool TWOCHILD>
 __global__ __launch_bounds__(64) void k_pixels(DevScene S, DevCam cam, DevParams P, const int* __restrict__ pixels,
                                                int n_pixels, int sample_sel, vrt_path_seg* __restrict__ segs,
                                                int cap, int* __restrict__ seg_counts, float4* __restrict__ rgba_out,
                                                int* __restrict__ hit_out, unsigned long long* ctr)
 {
-    int i = blockIdx.x * 64 + threadIdx.x;
+    const int pi = blockIdx.x;   // wave-uniform; the grid has exactly n_pixels blocks
+    const int lane = threadIdx.x;
     if (!TWOCHILD) P.general = 0;
     if (!BVH) stage_prims(S);
     stage_materials(S);
@@ -172,20 +181,59 @@ __global__ __launch_bounds__(64) void k_pixels(DevScene S, DevCam cam, DevParams
 #endif
     __shared__ LdsScene s_scene;
     stage_scene(S, &s_scene);
-    {   // every lane calls (the traversal re-cuts the wave); lanes beyond the list have no sample
-        const bool act = i < n_pixels;
-        const int pix = act ? pixels[i] : 0;
-        const int h = pix / cam.width, v = pix % cam.width;
-        Recorder R; R.segs = act ? segs + (size_t)i * cap : nullptr; R.cap = act ? cap : 0; R.n = 0; R.sample = 0;
-        int id;
-        const int i0 = !act ? 0 : (sample_sel < 0 ? 0 : sample_sel), i1 = !act ? 0 : (sample_sel < 0 ? P.spp : sample_sel + 1);
-        f3 sum = trace_samples_sm<BVH, true, TWOCHILD>(S, cam, P, &s_scene, h, v, i0, i1, id, C, R);
-        if (act) {
-            float4 c = process_color(sum / (float)(i1 - i0));
-            seg_counts[i] = R.n;
-            if (rgba_out) rgba_out[i] = c;
-            if (hit_out) hit_out[i] = id;
+    const int pix = pi < n_pixels ? pixels[pi] : 0;
+    const int h = pix / cam.width, v = pix % cam.width;
+    const int s0 = sample_sel < 0 ? 0 : sample_sel, s1 = sample_sel < 0 ? P.spp : sample_sel + 1;
+    f3 sum = mk3(0.f, 0.f, 0.f);
+    int id = -1, n_before = 0;   // segments of the samples of earlier rounds (wave-uniform)
+    for (int base = s0; base < s1; base += 64) {   // wave-uniform trip count
+        const int i = base + lane;
+        const bool act = i < s1;
+        int n_mine = 0, fp = -1;
+        f3 c = mk3(0.f, 0.f, 0.f);
+        for (int pass = 0; pass < 2; ++pass) {
+            // the counting pass's rays do not count: the counters are put back after it
+            unsigned keep = 0;
+            const Counters keepC = C;
+#if VRT_LDS_COUNTERS
+            if (pass == 0) { __syncthreads(); if (threadIdx.x < VRT_RAY_CLASSES) keep = g_lds_ctr[threadIdx.x]; }
+#endif
+            // where this lane's segments start: after those of the lanes before it, in sample order
+            int off = n_before;
+            if (pass == 1) {
+                int incl = n_mine;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
+                off = n_before + incl - n_mine;
+                n_before += __shfl(incl, 63, 64);
+            }
+            Recorder R;
+            R.n = 0; R.sample = 0;
+            const int room = cap > off ? cap - off : 0;
+            R.segs = (pass == 1 && act && room > 0) ? segs + (size_t)pi * cap + off : nullptr;
+            R.cap = (pass == 1 && act) ? room : 0;
+            c = trace_samples_sm<BVH, true, TWOCHILD>(S, cam, P, &s_scene, h, v, act ? i : 0, act ? i + 1 : 0, fp, C, R);
+            n_mine = act ? R.n : 0;
+            if (pass == 0) {
+                C = keepC;
+#if VRT_LDS_COUNTERS
+                __syncthreads();
+                if (threadIdx.x < VRT_RAY_CLASSES) g_lds_ctr[threadIdx.x] = keep;
+                __syncthreads();
+#endif
+            }
         }
+        if (base == 0 && lane == 0) id = fp;   // primary hit of sample 0
+        // the pixel's sum in sample order (RayTracerUnity.cs:580-592)
+        const int n_here = min(64, s1 - base);
+        for (int k = 0; k < n_here; ++k)
+            sum = sum + mk3(__shfl(c.x, k, 64), __shfl(c.y, k, 64), __shfl(c.z, k, 64));
+    }
+    if (lane == 0 && pi < n_pixels) {
+        float4 col = process_color(sum / (float)(s1 - s0));
+        seg_counts[pi] = n_before;
+        if (rgba_out) rgba_out[pi] = col;
+        if (hit_out) hit_out[pi] = id;
     }
     if (ctr) flush_counters(C, ctr, blockIdx.x);
 }
@@ -271,7 +319,7 @@ hipError_t vrt_launch_pixels(const DevScene& S, const DevCam& cam, const DevPara
                              hipStream_t stream)
 {
     if (n_pixels <= 0) return hipSuccess;
-    dim3 grid(div_up(n_pixels, 64)), block(64);
+    dim3 grid(n_pixels), block(64);   // one wave per pixel, its lanes are the pixel's samples
 #define VRT_GO(B, T) hipLaunchKernelGGL((k_pixels<B, T>), grid, block, 0, stream, S, cam, P, pixels, n_pixels, sample_sel, segs, cap, seg_counts, rgba_out, hit_out, ctr)
     if (bvh) { if (twochild) VRT_GO(true, true); else VRT_GO(true, false); }
 #if VRT_SLAB_FMA
