@@ -90,8 +90,10 @@ __global__ __launch_bounds__(VRT_MEGA_THREADS, BVH ? VRT_BVH_WAVES : (SIMPLE ? V
     const bool inside = v < cam.width && r < P.local_rows && h < cam.height;
     // see VRT_USE_SM in vrt_trace.h
     constexpr bool USE_SM = VRT_USE_SM == 1 || (VRT_USE_SM == 2 && BVH);
+    // paths a thinned-out wave finishes together in the state machine (VRT_TAIL_MAX in vrt_trace.h)
+    constexpr bool TAIL = BVH && !TWOCHILD && !USE_SM && VRT_TAIL_MAX > 0;
     __shared__ LdsScene s_scene;
-    if constexpr (USE_SM) stage_scene(S, &s_scene);
+    if constexpr (USE_SM || TAIL) stage_scene(S, &s_scene);
     f3 sum = mk3(0.f, 0.f, 0.f);
     int id = -1;
     for (int base = 0; base < P.spp; base += n_sl) {   // wave-uniform trip count
@@ -116,7 +118,18 @@ __global__ __launch_bounds__(VRT_MEGA_THREADS, BVH ? VRT_BVH_WAVES : (SIMPLE ? V
             // the whole wave goes in, so that the camera rays can be traced cooperatively
             const bool live = inside && i < P.spp;
             int fp;
-            c = trace_sample_dev<BVH, false, TWOCHILD>(S, cam, P, raw, off, i, fp, C, R, live, true);
+            if constexpr (TAIL) {
+                PathState ps;
+                ps.pending = false;
+                c = trace_sample_dev<BVH, false, TWOCHILD>(S, cam, P, raw, off, i, fp, C, R, live, true, &ps);
+                if (__any(ps.pending)) {   // wave-uniform: all 64 lanes go in, those with a path to finish take it up
+                    int unused;
+                    const f3 t = trace_samples_sm<BVH, false, TWOCHILD>(S, cam, P, &s_scene, 0, 0, 0, ps.pending ? 1 : 0, unused, C, R, &ps);
+                    if (ps.pending) c = t;
+                }
+            } else {
+                c = trace_sample_dev<BVH, false, TWOCHILD>(S, cam, P, raw, off, i, fp, C, R, live, true);
+            }
             if (live && i == 0) id = fp;
         } else if (inside && i < P.spp) {
             int fp;

@@ -1268,10 +1268,18 @@ struct Counters { unsigned precheck, primary, reflect, transmit, shadow, ao; };
 #ifndef VRT_STUDY_NO_ANYHIT
 #define VRT_STUDY_NO_ANYHIT 0
 #endif
+// VRT_STUDY_LIVE_HIST=1 (study build): the counter words report, instead of rays per class, how many
+// turns of the bounce loop ran with 1, 2, 3-4, 5-8, 9-16, 17-32, 33-48, 49-64 lanes of the wave on a path.
+#ifndef VRT_STUDY_LIVE_HIST
+#define VRT_STUDY_LIVE_HIST 0
+#endif
 #if VRT_LDS_COUNTERS
 __shared__ unsigned g_lds_ctr[VRT_RAY_CLASSES];
 __device__ __forceinline__ void count_event(int k)
 {
+#if VRT_STUDY_LIVE_HIST
+    return;
+#endif
     unsigned long long m = __ballot(1);
     if ((int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) atomicAdd(&g_lds_ctr[k], (unsigned)__popcll(m));
 }
@@ -1734,16 +1742,35 @@ __device__ __forceinline__ void store_pixel(const DevParams& P, float4* rgba, si
 
 struct PendingRay { f3 o, d, T; int depth, skip, kind; };
 
+// A path handed over before its next ray is cast: origin and direction of that ray, throughput and
+// radiance so far, the depth the ray is cast at and the primitive it leaves.
+struct PathState { f3 o, d, T, L; int depth, skip; bool pending; };
+
+// VRT_TAIL_MAX > 0 (tree scenes, one child per hit): once at most that many lanes of a wave are still
+// on a path, they leave the per-lane bounce loop with their paths unfinished, and the wave finishes
+// them together in the single-loop state machine, whose one traversal site gives every query four
+// lanes (intersect_bvh4_quads).  A per-lane traversal step costs the wave the same ~120 vector
+// instructions whether 1 or 64 lanes take it; on the 10k-sphere frame 41 % of the turns of the bounce
+// loop run with 16 lanes or fewer.  Built, bit-identical, and measured slower on MI355X whatever the
+// threshold (10k spheres 4K x 16 spp: 24.6 ms without, 29.2 / 29.5 / 29.1 ms with 1 / 4 / 16; 1M
+// triangles 2.07 -> 2.46 ms): the state machine's registers come on top of the frame kernel's (87
+// spilled VGPRs instead of 22), and handing 41 % of the turns to it instead of none changes 0.1 ms.
+// A study switch, 0 = off.
+#ifndef VRT_TAIL_MAX
+#define VRT_TAIL_MAX 0
+#endif
+
 // Tracer/WhittedTracer.cs:33-104 as an iterative loop: radiance is accumulated as
 // sum(throughput * direct term) instead of unwinding a recursion; the second child of a
 // refracting hit waits on a bounded per-lane stack.
-template <bool BVH, bool RECORD, bool TWOCHILD>
+template <bool BVH, bool RECORD, bool TWOCHILD, bool TAIL = false>
 // shaded: the first hit has been shaded already (its Bounce), the loop starts at its children.
+// TAIL: see VRT_TAIL_MAX; *ps receives the unfinished path (the function then returns early).
 // L0, T0: radiance gathered and throughput reached before (o, d) was cast (a path taken up after its
 // first bounce); the sums go on in the order of the path traced from the camera, so the bits agree.
 __device__ __forceinline__ f3 trace_path(const DevScene& S, const DevParams& P, f3 o, f3 d, Hit first,
                                          Counters& C, Recorder& R, int depth0 = 0, const Bounce* shaded = nullptr,
-                                         f3 L0 = {0.f, 0.f, 0.f}, f3 T0 = {1.f, 1.f, 1.f})
+                                         f3 L0 = {0.f, 0.f, 0.f}, f3 T0 = {1.f, 1.f, 1.f}, PathState* ps = nullptr)
 {
     f3 L = L0;
     f3 T = T0;
@@ -1756,6 +1783,22 @@ __device__ __forceinline__ f3 trace_path(const DevScene& S, const DevParams& P, 
     PendingRay stack[TWOCHILD ? VRT_MAX_DEPTH + 2 : 1];
     int sp = 0;
     for (;;) {
+#if VRT_STUDY_LIVE_HIST   // study build: how many lanes of the wave are still on a path, per turn of this loop
+        {
+            const unsigned long long m = __ballot(1);
+            const int n = __popcll(m);
+            const int bucket = n <= 1 ? 0 : n <= 2 ? 1 : n <= 4 ? 2 : n <= 8 ? 3 : n <= 16 ? 4 : n <= 32 ? 5 : n <= 48 ? 6 : 7;
+            if ((int)(threadIdx.x & 63) == __ffsll((long long)m) - 1)
+                atomicAdd(&S.dbg[(blockIdx.x % VRT_CTR_SLOTS) * VRT_CTR_STRIDE + bucket], 1ull);
+        }
+#endif
+        if constexpr (TAIL && !TWOCHILD) {
+            // the lanes still in this loop are the active ones here
+            if (!have_B && !have_first && __popcll(__ballot(1)) <= VRT_TAIL_MAX) {
+                ps->o = o; ps->d = d; ps->T = T; ps->L = L; ps->depth = depth; ps->skip = skip; ps->pending = true;
+                return L;
+            }
+        }
         if (!have_B) {
             if (!have_first) {
                 h.prim = -1; h.t = INFINITY; h.aux = 0;
@@ -1802,7 +1845,7 @@ __device__ __forceinline__ f3 trace_path(const DevScene& S, const DevParams& P, 
 template <bool BVH, bool RECORD, bool TWOCHILD>
 __device__ __forceinline__ f3 trace_sample_dev(const DevScene& S, const DevCam& cam, const DevParams& P, f3 raw,
                                                const float2* off, int i, int& first_prim, Counters& C, Recorder& R,
-                                               bool live = true, bool wave = false)
+                                               bool live = true, bool wave = false, PathState* ps = nullptr)
 {
     // wave: all 64 lanes of the wave are here (live tells which hold a sample), so the camera rays
     // can be traced with the wave-cooperative forms
@@ -1854,6 +1897,9 @@ __device__ __forceinline__ f3 trace_sample_dev(const DevScene& S, const DevCam& 
                 if (hit) {
                     const f3 L0 = mk3(0.f, 0.f, 0.f) + mk3(1.f, 1.f, 1.f) * B.A;
                     if (!go) return L0;
+                    if constexpr (VRT_TAIL_MAX > 0) {
+                        if (ps) return trace_path<BVH, false, TWOCHILD, true>(S, P, B.o, B.d0, h1, C, R, 1, nullptr, L0, mk3(1.f, 1.f, 1.f) * B.w0, ps);
+                    }
                     return trace_path<BVH, false, TWOCHILD>(S, P, B.o, B.d0, h1, C, R, 1, nullptr, L0, mk3(1.f, 1.f, 1.f) * B.w0);
                 }
                 if (!live) return mk3(0.f, 0.f, 0.f);
@@ -1986,8 +2032,10 @@ __device__ __forceinline__ f3 light_term(const DevLight& l, f3 wi, float ndotwi,
 template <bool BVH, bool RECORD, bool TWOCHILD>
 __device__ __forceinline__ f3 trace_samples_sm(const DevScene& S, const DevCam& cam, const DevParams& P,
                                                const LdsScene* lds, int ph, int pv, int i0, int i1,
-                                               int& hit_id, Counters& C, Recorder& R)
+                                               int& hit_id, Counters& C, Recorder& R, const PathState* resume = nullptr)
 {
+    // resume: instead of samples, a lane with resume->pending (and i1 = i0 + 1) takes up the path
+    // handed over there, at the ray that is cast next; its radiance is what the function returns
     const vrt_shading& sh = S.sh;
     const f3 O = mk3(cam.ox, cam.oy, cam.oz);
     const f3 raw = camera_raw_dir(cam, ph, pv);
@@ -2013,9 +2061,17 @@ __device__ __forceinline__ f3 trace_samples_sm(const DevScene& S, const DevCam& 
     int sp = 0;
     int st = ST_SAMPLE;
     bool done = false;
+    bool seeded = false;   // the first turn starts with a query already waiting
+    if (resume != nullptr && i0 < i1) {
+        T = resume->T; L = resume->L; depth = resume->depth; kind = VRT_RAY_REFLECT;
+        qo = resume->o; qd = resume->d; qskip = resume->skip;
+        st = ST_CLOSEST;
+        if (!is_zero3(qd)) { VRT_COUNT(C, reflect, VRT_RAY_REFLECT); seeded = true; }
+    }
 
     for (;;) {
-        bool query = false;
+        bool query = seeded;
+        seeded = false;
         while (!query && !done) {
             if (st == ST_SAMPLE) {
                 if (i >= i1) { done = true; continue; }
