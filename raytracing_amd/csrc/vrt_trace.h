@@ -27,14 +27,25 @@ __device__ __forceinline__ f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y 
 __device__ __forceinline__ f3 operator-(f3 a) { return mk3(-a.x, -a.y, -a.z); }
 __device__ __forceinline__ f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
 __device__ __forceinline__ f3 operator*(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+#ifndef VRT_STUDY_FAST_DIV
+#define VRT_STUDY_FAST_DIV 0
+#endif
+#if VRT_STUDY_FAST_DIV   // timing study only (results differ): what the IEEE divisions and square roots of the vector helpers cost
+__device__ __forceinline__ f3 operator/(f3 a, float s) { const float r = __builtin_amdgcn_rcpf(s); return mk3(a.x * r, a.y * r, a.z * r); }
+#else
 __device__ __forceinline__ f3 operator/(f3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s); }
+#endif
 // UnityEngine.Vector3.Dot / Cross / Magnitude / Normalize
 __device__ __forceinline__ float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 __device__ __forceinline__ f3 cross3(f3 a, f3 b)
 {
     return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
+#if VRT_STUDY_FAST_DIV
+__device__ __forceinline__ float mag3(f3 a) { return __builtin_amdgcn_sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }
+#else
 __device__ __forceinline__ float mag3(f3 a) { return sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }
+#endif
 __device__ __forceinline__ f3 normalize3(f3 a)
 {
     float m = mag3(a);
