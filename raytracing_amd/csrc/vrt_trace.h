@@ -5,6 +5,7 @@
 // Citations: /root/reference/VisualRayTrace/Assets/Scripts/RayTracer/<file>:<lines>.
 #pragma once
 #include "vrt_device.h"
+#include "vrt_exact_math.h"
 
 // VRT_USE_SM selects the tracer of the frame kernel: 0 the straight-line tracer (trace_sample_dev),
 // 1 the single-loop state machine (trace_samples_sm), 2 the state machine for tree scenes only.
@@ -30,8 +31,36 @@ __device__ __forceinline__ f3 operator*(f3 a, f3 b) { return mk3(a.x * b.x, a.y 
 #ifndef VRT_STUDY_FAST_DIV
 #define VRT_STUDY_FAST_DIV 0
 #endif
+// VRT_SHORT_MATH=1: square roots, reciprocals and divisions of the vector helpers take the short forms
+// of vrt_exact_math.h (the compiler's own expansions without their scaling and fix-up steps: 9 instead
+// of 16, 3 instead of 11 and 5 instead of 11 instructions, the reciprocal shared by the components
+// of a vector) whenever no operand of any lane of the wave needs those steps, which a handful of
+// instructions decide; otherwise the wave takes the compiler's form.  Same values either way (all GPU
+// tests pass with it), but not faster on MI355X: teaching scene 0.1112 -> 0.1116 ms, 10k spheres 24.6 ->
+// 25.1 ms, 1M triangles 2.07 -> 2.10 ms; the test and the second code path cost what the shorter
+// sequences save (with approximate forms and no test the bound is -13.6 % / -4.1 %).  A study switch, off.
+#ifndef VRT_SHORT_MATH
+#define VRT_SHORT_MATH 0
+#endif
 #if VRT_STUDY_FAST_DIV   // timing study only (results differ): what the IEEE divisions and square roots of the vector helpers cost
 __device__ __forceinline__ f3 operator/(f3 a, float s) { const float r = __builtin_amdgcn_rcpf(s); return mk3(a.x * r, a.y * r, a.z * r); }
+#elif VRT_SHORT_MATH
+// a.x / s, a.y / s, a.z / s, correctly rounded.  Short form when, for every lane that is here, s lies in
+// [2^-40, 2^40] and every component of a is zero or lies in that range too: then the division needs
+// no scaling, and one refined reciprocal of s serves all three.  (w maps |a| to 2|a|-2 as integers, which
+// sends zero to the top of the range: a component is too small iff 0 < |a| < 2^-40.)
+__device__ __forceinline__ f3 operator/(f3 a, float s)
+{
+    const unsigned wx = (__float_as_uint(a.x) << 1) - 2u, wy = (__float_as_uint(a.y) << 1) - 2u, wz = (__float_as_uint(a.z) << 1) - 2u;
+    const unsigned wmin = min(min(wx, wy), wz);
+    const float amax = fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fabsf(a.z));
+    const bool ok = wmin >= ((87u << 23) << 1) - 2u && amax <= 0x1p40f && __builtin_amdgcn_fmed3f(s, 0x1p-40f, 0x1p40f) == s;
+    if (__all(ok)) {
+        const float r = vrt_rcp_short(s);
+        return mk3(vrt_div_short(a.x, s, r), vrt_div_short(a.y, s, r), vrt_div_short(a.z, s, r));
+    }
+    return mk3(a.x / s, a.y / s, a.z / s);
+}
 #else
 __device__ __forceinline__ f3 operator/(f3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s); }
 #endif
@@ -41,10 +70,27 @@ __device__ __forceinline__ f3 cross3(f3 a, f3 b)
 {
     return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
+// sqrtf(x): the short form where x needs no scaling in any lane that is here.
+__device__ __forceinline__ float sqrt_ieee(float x)
+{
+#if VRT_SHORT_MATH && !VRT_STUDY_FAST_DIV
+    if (__all(__builtin_amdgcn_fmed3f(x, 0x1p-80f, 0x1p80f) == x)) return vrt_sqrt_short(x);
+#endif
+    return sqrtf(x);
+}
+// 1 / x per component, correctly rounded; the short form where every component of every lane lies in +-[2^-40, 2^40].
+__device__ __forceinline__ f3 rcp3_ieee(f3 d)
+{
+#if VRT_SHORT_MATH && !VRT_STUDY_FAST_DIV
+    const float lo = fminf(fminf(fabsf(d.x), fabsf(d.y)), fabsf(d.z)), hi = fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fabsf(d.z));
+    if (__all(lo >= 0x1p-40f && hi <= 0x1p40f)) return mk3(vrt_rcp_short(d.x), vrt_rcp_short(d.y), vrt_rcp_short(d.z));
+#endif
+    return mk3(1.f / d.x, 1.f / d.y, 1.f / d.z);
+}
 #if VRT_STUDY_FAST_DIV
 __device__ __forceinline__ float mag3(f3 a) { return __builtin_amdgcn_sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }
 #else
-__device__ __forceinline__ float mag3(f3 a) { return sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }
+__device__ __forceinline__ float mag3(f3 a) { return sqrt_ieee(a.x * a.x + a.y * a.y + a.z * a.z); }
 #endif
 __device__ __forceinline__ f3 normalize3(f3 a)
 {
@@ -342,7 +388,7 @@ __device__ __forceinline__ Hit intersect_brute(const DevScene& S, f3 o, f3 d, fl
     }
     if (S.all_aab) {
         // every box is aligned with the world axes: one reciprocal per ray component serves all
-        const f3 inv = mk3(1.f / d.x, 1.f / d.y, 1.f / d.z);
+        const f3 inv = rcp3_ieee(d);
         for (int i = 0; i < S.n_box; ++i) {
             float t;
             const float4 a0 = VRT_AAB(2 * i), a1 = VRT_AAB(2 * i + 1);
@@ -1533,8 +1579,8 @@ __device__ __forceinline__ f3 phong_shade(const DevScene& S, const DevParams& P,
         f3 wi;
         if (l.type == VRT_LIGHT_POINT) {
             f3 tmp = lp - point;
-            float len = sqrtf(tmp.x * tmp.x + tmp.y * tmp.y + tmp.z * tmp.z);
-            wi = mk3(tmp.x / len, tmp.y / len, tmp.z / len);
+            float len = sqrt_ieee(tmp.x * tmp.x + tmp.y * tmp.y + tmp.z * tmp.z);
+            wi = tmp / len;
         } else {
             wi = lp;
         }
@@ -2056,8 +2102,8 @@ __device__ __forceinline__ f3 light_wi(const DevLight& l, f3 point)
     f3 lp = mk3(l.vx, l.vy, l.vz);
     if (l.type == VRT_LIGHT_POINT) {
         f3 tmp = lp - point;
-        float len = sqrtf(tmp.x * tmp.x + tmp.y * tmp.y + tmp.z * tmp.z);
-        return mk3(tmp.x / len, tmp.y / len, tmp.z / len);
+        float len = sqrt_ieee(tmp.x * tmp.x + tmp.y * tmp.y + tmp.z * tmp.z);
+        return tmp / len;
     }
     return lp;
 }
