@@ -18,8 +18,8 @@
 // One wave per block measured 6 % faster than four (finer-grained tail).
 // Every variant is compiled for 4 waves per SIMD (128 VGPRs).  The tree variant needs them for
 // the packed slab arithmetic of the 4-wide traversal, whose operands live in register pairs: at
-// 5 waves (96 VGPRs) it spills and loses 24 %, at 3 waves it loses 9 % to latency.  The
-// brute-force variants fit 106-124 registers; 5 waves gain 1 % and add scratch traffic.
+// 5 waves (96 VGPRs) it spills and loses 24 %, at 3 waves it loses 9 % to latency.  The general
+// brute-force variants fit 106-124 registers and stay at 4 waves; see VRT_SIMPLE_WAVES for the others.
 // P.xcd_remap (off by default, see vrt_api.hip) renumbers blocks so that the 8 blocks dealt
 // round-robin to the 8 XCDs come from 8 separate bands of the image.
 namespace VRT_FORM {
@@ -28,8 +28,12 @@ namespace VRT_FORM {
 #ifndef VRT_BVH_WAVES
 #define VRT_BVH_WAVES 4
 #endif
+// The instantiations for simple brute-force scenes run at 5 waves per SIMD (96 VGPRs, two of them
+// spilled): the kernel issues a vector instruction in 44 % of the slots a SIMD has (a wave waits for
+// the scalar loads of the primitives and for its own dependent chains), and a fifth wave fills some of
+// them: teaching scene at 1080p 0.1111 -> 0.1009 ms; 6 waves (80 VGPRs, 29 spilled) 0.1022 ms.
 #ifndef VRT_SIMPLE_WAVES
-#define VRT_SIMPLE_WAVES 4
+#define VRT_SIMPLE_WAVES 5
 #endif
 // SIMPLE (brute-force scenes only) is the instantiation for scenes of spheres and world-axis boxes
 // without triangles or textures, such as the shipped teaching scene: with those facts known at
