@@ -491,6 +491,13 @@ static int build_scene(vrt_ctx* c, const vrt_scene_desc* d, SceneBufs& sb)
     HIPCHK(c, upload(&sb.d_lights, lights));
     S.lights = sb.d_lights;
     S.sh = d->shading;
+    for (int k = 0; k < 3; ++k) {   // see DevScene: same float operations, in the order of the shading code
+        const vrt_shading& sh = d->shading;
+        S.ao_free[k] = sh.ao_color[k] * sh.ao_ls;
+        const float mn_ls = sh.ao_min_amount[k] * sh.ao_ls;
+        S.ao_occl[k] = mn_ls * sh.ao_color[k];
+        S.metal_w[k] = sh.metal_cr[k] * sh.metal_kr;
+    }
     S.dbg = c->d_ctr;
     S.stack_cap = VRT_TRAV_STACK;
     for (uint32_t i = 0; i < d->n_materials; ++i) {

@@ -69,6 +69,11 @@ struct DevScene {
     unsigned long long* dbg; // the context's counter block (slots 6, 7: nodes entered, primitives tested)
     int stack_cap;           // traversal-stack entries per lane in use: VRT_TRAV_STACK (vrt_trace.h) unless a test shortens it
     int has_matte, has_transparent; // some material is of class VRT_MAT_MATTE / VRT_MAT_TRANSPARENT
+    // Products of shading constants, formed once on the host with the float operations the shading code
+    // would use (one rounding per multiply): the ambient occluder's radiance unoccluded (color * ls) and
+    // occluded ((min_amount * ls) * color), the mirror's cr * kr.  Wave-uniform products formed in the
+    // kernel are hoisted to its start, kept in vector registers and spilled by every wave.
+    float ao_free[3], ao_occl[3], metal_w[3];
     vrt_shading sh;
 };
 

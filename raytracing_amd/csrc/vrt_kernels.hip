@@ -25,6 +25,10 @@
 namespace VRT_FORM {
 
 #define VRT_MEGA_THREADS 64
+// VRT_KEEP_LDS=1: see KEEP_LDS in k_mega.
+#ifndef VRT_KEEP_LDS
+#define VRT_KEEP_LDS 1
+#endif
 #ifndef VRT_BVH_WAVES
 #define VRT_BVH_WAVES 4
 #endif
@@ -73,16 +77,26 @@ __global__ __launch_bounds__(VRT_MEGA_THREADS, BVH ? VRT_BVH_WAVES : (SIMPLE ? V
         tile = bid;
     }
     const int bx = bid % blocks_x, by = bid / blocks_x;
-    const int lane = threadIdx.x;
     // SPLIT = false is the instantiation for one lane per pixel (sample_shift 0)
     const int shift = !SPLIT ? 0 : P.sample_shift;
     const int n_sl = 1 << shift;                       // sample lanes per pixel
     const int pshift = 6 - shift;                      // log2(pixels per wave)
     const int pw_shift = (pshift + 1) >> 1;            // tile width 2^ceil(pshift/2), height 2^floor(pshift/2)
-    const int pi = lane >> shift, si = lane & (n_sl - 1);
-    const int v = (bx << pw_shift) + (pi & ((1 << pw_shift) - 1));
-    const int r = (by << (pshift - pw_shift)) + (pi >> pw_shift);
-    const int h = local_to_global_row(P, r);
+    // Tree kernels (KEEP_LDS): what a lane knows about its pixel is worked out again where it is needed
+    // (per round, and for the store at the end) from a lane number the compiler cannot see through,
+    // and the pixel's sum waits in LDS while a round is traced: values that live across the tracing
+    // code would otherwise be spilled to scratch memory by every wave, 6 KB each, which at 512 resident
+    // waves per XCD is most of that XCD's L2 and ends up as gigabytes of write-backs per frame.
+    constexpr bool KEEP_LDS = BVH && VRT_KEEP_LDS;
+    int lane = threadIdx.x;
+#define VRT_PIXEL_OF_LANE()                                                        \
+    DevParams Pl = P;   /* divisors hidden too: the invariant halves of divisions by them would be hoisted and kept */ \
+    if constexpr (KEEP_LDS) asm volatile("" : "+v"(lane), "+s"(Pl.tile_rows), "+s"(Pl.tile_count), "+s"(Pl.n_sets)); \
+    const int pi = lane >> shift, si = lane & (n_sl - 1);                          \
+    const int v = (bx << pw_shift) + (pi & ((1 << pw_shift) - 1));                 \
+    const int r = (by << (pshift - pw_shift)) + (pi >> pw_shift);                  \
+    const int h = local_to_global_row(Pl, r);                                      \
+    const bool inside = v < cam.width && r < P.local_rows && h < cam.height;
     if (!BVH) stage_prims(S);
     stage_materials(S);
     Counters C = {0, 0, 0, 0, 0, 0};
@@ -91,7 +105,7 @@ __global__ __launch_bounds__(VRT_MEGA_THREADS, BVH ? VRT_BVH_WAVES : (SIMPLE ? V
     __syncthreads();
 #endif
     Recorder R; R.segs = nullptr; R.cap = 0; R.n = 0; R.sample = 0;
-    const bool inside = v < cam.width && r < P.local_rows && h < cam.height;
+    __shared__ float s_keep[KEEP_LDS ? 4 : 1][VRT_MEGA_THREADS];   // the pixel's sum and hit id between rounds
     // see VRT_USE_SM in vrt_trace.h
     constexpr bool USE_SM = VRT_USE_SM == 1 || (VRT_USE_SM == 2 && BVH);
     // paths a thinned-out wave finishes together in the state machine (VRT_TAIL_MAX in vrt_trace.h)
@@ -100,16 +114,25 @@ __global__ __launch_bounds__(VRT_MEGA_THREADS, BVH ? VRT_BVH_WAVES : (SIMPLE ? V
     if constexpr (USE_SM || TAIL) stage_scene(S, &s_scene);
     f3 sum = mk3(0.f, 0.f, 0.f);
     int id = -1;
+    if constexpr (KEEP_LDS) {
+        s_keep[0][threadIdx.x] = 0.f; s_keep[1][threadIdx.x] = 0.f; s_keep[2][threadIdx.x] = 0.f;
+        s_keep[3][threadIdx.x] = __int_as_float(-1);
+    }
     for (int base = 0; base < P.spp; base += n_sl) {   // wave-uniform trip count
+        VRT_PIXEL_OF_LANE()
         const int i = base + si;
         f3 c = mk3(0.f, 0.f, 0.f);
         // per round, not hoisted: these would otherwise stay in registers through every traversal
         f3 raw = mk3(0.f, 0.f, 0.f);
         const float2* off = nullptr;
         if (inside && !USE_SM) {
-            raw = camera_raw_dir(cam, h, v);
+            DevCam camr = cam;
+            // (the image size hidden as well: the loop-invariant halves of the two divisions in
+            // camera_raw_dir would be hoisted out of the loop and kept in vector registers)
+            if constexpr (KEEP_LDS) asm volatile("" : "+s"(camr.width), "+s"(camr.height));
+            raw = camera_raw_dir(camr, h, v);
             unsigned pixel = (unsigned)(h * cam.width + v);
-            unsigned set = pixel_set_dev(P.seed, pixel, (unsigned)P.n_sets);
+            unsigned set = pixel_set_dev(P.seed, pixel, (unsigned)Pl.n_sets);
             off = P.offsets ? P.offsets + (size_t)set * P.spp : nullptr;
         }
         if constexpr (USE_SM) {
@@ -140,6 +163,10 @@ __global__ __launch_bounds__(VRT_MEGA_THREADS, BVH ? VRT_BVH_WAVES : (SIMPLE ? V
             c = trace_sample_dev<BVH, false, TWOCHILD>(S, cam, P, raw, off, i, fp, C, R);
             if (i == 0) id = fp;
         }
+        if constexpr (KEEP_LDS) {   // the sum so far comes back from LDS (the barrier keeps the load after the tracing code)
+            asm volatile("" ::: "memory");
+            sum = mk3(s_keep[0][threadIdx.x], s_keep[1][threadIdx.x], s_keep[2][threadIdx.x]);
+        }
         if (shift == 0) {
             sum = sum + c;
         } else {
@@ -152,14 +179,28 @@ __global__ __launch_bounds__(VRT_MEGA_THREADS, BVH ? VRT_BVH_WAVES : (SIMPLE ? V
                 sum = sum + q;
             }
         }
+        if constexpr (KEEP_LDS) {
+            s_keep[0][threadIdx.x] = sum.x; s_keep[1][threadIdx.x] = sum.y; s_keep[2][threadIdx.x] = sum.z;
+            if (id != -1) s_keep[3][threadIdx.x] = __int_as_float(id);   // set in the round of sample 0, by that sample's lane
+            sum = mk3(0.f, 0.f, 0.f); id = -1;                           // nothing is carried in registers
+            asm volatile("" ::: "memory");
+        }
     }
-    if (inside && si == 0) {
-        // x / 1 is x: one sample per pixel needs no IEEE divisions (a wave-uniform branch)
-        f3 fin = P.spp == 1 ? sum : sum / (float)P.spp;
-        size_t idx = (size_t)(P.compact ? r : h) * cam.width + v; // RayTracerUnity.cs:442
-        store_pixel(P, rgba, idx, fin);
-        if (hit_id) hit_id[idx] = id;
+    {
+        VRT_PIXEL_OF_LANE()
+        if constexpr (KEEP_LDS) {
+            sum = mk3(s_keep[0][threadIdx.x], s_keep[1][threadIdx.x], s_keep[2][threadIdx.x]);
+            id = __float_as_int(s_keep[3][threadIdx.x]);
+        }
+        if (inside && si == 0) {
+            // x / 1 is x: one sample per pixel needs no IEEE divisions (a wave-uniform branch)
+            f3 fin = P.spp == 1 ? sum : sum / (float)P.spp;
+            size_t idx = (size_t)(P.compact ? r : h) * cam.width + v; // RayTracerUnity.cs:442
+            store_pixel(P, rgba, idx, fin);
+            if (hit_id) hit_id[idx] = id;
+        }
     }
+#undef VRT_PIXEL_OF_LANE
     flush_counters(C, ctr, blockIdx.x);
     if constexpr (BVH || ORD == 2) {
         if (P.tile_cost && threadIdx.x == 0) P.tile_cost[tile] = (unsigned)(clock64() - t_start);

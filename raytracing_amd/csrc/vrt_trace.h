@@ -1553,6 +1553,13 @@ __device__ __forceinline__ f3 ambient_L(const DevScene& S, const DevParams& P, f
             }
         }
     }
+    // (min_amount * ls) * color when occluded, else color * ls.  The tree kernels take the products the
+    // host formed (DevScene): formed here they are hoisted to the kernel's start and spilled by every
+    // wave.  The brute-force kernels have the registers, and nine more scalars would cost them 1 %.
+    if constexpr (BVH) {
+        if (occluded) return mk3(S.ao_occl[0], S.ao_occl[1], S.ao_occl[2]);
+        return mk3(S.ao_free[0], S.ao_free[1], S.ao_free[2]);
+    }
     const vrt_shading& sh = S.sh;
     f3 lc = mk3(sh.ao_color[0], sh.ao_color[1], sh.ao_color[2]);
     if (occluded) {
@@ -1757,14 +1764,18 @@ __device__ __forceinline__ void shade_hit(const DevScene& S, const DevParams& P,
         float ndotwo = dot3(n, wo);
         f3 wi = (-wo) + (n * 2.f) * ndotwo;
         float nd = dot3(n, wi);
-        f3 fr = (mk3(sh.metal_cr[0], sh.metal_cr[1], sh.metal_cr[2]) * sh.metal_kr) / fabsf(nd);
+        // (cr * kr) / |n.wi|, the product from the host in the tree kernels (see ambient_L)
+        f3 fr = (BVH ? mk3(S.metal_w[0], S.metal_w[1], S.metal_w[2])
+                     : mk3(sh.metal_cr[0], sh.metal_cr[1], sh.metal_cr[2]) * sh.metal_kr) / fabsf(nd);
         n_child = 1; d0 = normalize3(wi); w0 = fr * nd;
     } else if (glass) {
         f3 wo = -d;
         float ndotwo = dot3(n, wo);
         f3 wi = (-wo) + (n * 2.f) * ndotwo;
         n_child = 1; d0 = normalize3(wi); w0 = mk3(1.f, 1.f, 1.f);
-        if (P.flags & VRT_FIX_DIELECTRIC) {
+        // (P.general: the flag sends a frame to the kernels that follow two children per hit, and the
+        // others need not carry this code, nor its wave-uniform eta in a register)
+        if (P.general && (P.flags & VRT_FIX_DIELECTRIC)) {
             float eta = sh.glass_eta_in / sh.glass_eta_out;
             float ci = dot3(n, wo);
             f3 nn = n;
@@ -2220,17 +2231,15 @@ __device__ __forceinline__ f3 trace_samples_sm(const DevScene& S, const DevCam& 
                         st = ST_AO; query = true;
                     } else {
                         MatK k = material_consts(lds, mtype);
-                        A = (cd * k.ka) * (mk3(sh.ao_color[0], sh.ao_color[1], sh.ao_color[2]) * sh.ao_ls);
+                        A = (cd * k.ka) * mk3(S.ao_free[0], S.ao_free[1], S.ao_free[2]);
                         light = 0; st = ST_LIGHTS;
                     }
                 }
             } else if (st == ST_AO) {
                 record_seg<RECORD>(R, qo, qd, h, VRT_RAY_AO, depth, P.range);
                 MatK k = material_consts(lds, mtype);
-                f3 lc = mk3(sh.ao_color[0], sh.ao_color[1], sh.ao_color[2]);
-                f3 aoL = lc * sh.ao_ls;
-                if (h.prim >= 0)
-                    aoL = (mk3(sh.ao_min_amount[0], sh.ao_min_amount[1], sh.ao_min_amount[2]) * sh.ao_ls) * lc;
+                f3 aoL = mk3(S.ao_free[0], S.ao_free[1], S.ao_free[2]);
+                if (h.prim >= 0) aoL = mk3(S.ao_occl[0], S.ao_occl[1], S.ao_occl[2]);
                 A = (cd * k.ka) * aoL;
                 light = 0; st = ST_LIGHTS;
             } else if (st == ST_LIGHTS) {
@@ -2278,7 +2287,7 @@ __device__ __forceinline__ f3 trace_samples_sm(const DevScene& S, const DevCam& 
                     n_child = 1; d0 = normalize3(wi);
                     if (mtype == VRT_MAT_METAL) {
                         float nd = dot3(n, wi);
-                        f3 fr = (mk3(sh.metal_cr[0], sh.metal_cr[1], sh.metal_cr[2]) * sh.metal_kr) / fabsf(nd);
+                        f3 fr = mk3(S.metal_w[0], S.metal_w[1], S.metal_w[2]) / fabsf(nd);
                         w0 = fr * nd;
                     } else {
                         w0 = mk3(1.f, 1.f, 1.f);
