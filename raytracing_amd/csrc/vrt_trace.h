@@ -462,11 +462,12 @@ __device__ __forceinline__ bool slab_test(f3 lo, f3 hi, f3 o, f3 inv, float tmax
 #ifndef VRT_STACK_LANES
 #define VRT_STACK_LANES 64
 #endif
-// VRT_CC_EARLY=1 (study) keeps the load of a node's child codes with the loads of its planes
-// instead of inside the "some child is hit" branch: +0.1 % / +0.7 % on the two tree workloads, but
-// five more spilled registers and 2.8 GiB more scratch writes per 4K x 16 spp frame; off.
+// VRT_CC_EARLY=1 keeps the load of a node's child codes with the loads of its planes instead of
+// inside the "some child is hit" branch, where it is a second memory round trip on the way to the
+// next node.  It needs four registers more; since the frame kernel stopped spilling it has them:
+// 10k spheres 23.92 -> 23.73 ms, 1M triangles 2.010 -> 1.980 ms.
 #ifndef VRT_CC_EARLY
-#define VRT_CC_EARLY 0
+#define VRT_CC_EARLY 1
 #endif
 // VRT_PUSH_BRANCHLESS (study; 1: any-hit traversals, 2: closest-hit ones as well): trav_inner leaves
 // its children on the stack without branches; every push is a store, and the stores that are not to
