@@ -172,7 +172,7 @@ def tree_roofline(workload, scene, st, rays, queries, kernel_ms, fb_bytes):
                              "excluded) against the FP32 vector peak; node and primitive loads against the vector-L1 "
                              "rate; measured HBM bytes in `traffic`.  Camera rays and the occlusion rays of their hits "
                              "walk the tree once per wave (a frontier node counts once, not once per ray), so fewer "
-                             "box tests are executed per ray than a per-ray traversal needs (4.8 instead of 16.5 nodes "
+                             "box tests are executed per ray than a per-ray traversal needs (2.8 instead of 16.5 nodes "
                              "on the 10k-sphere frame) and `frac` falls while the frame gets faster; `profiled` holds "
                              "the issue-slot share and lane activity of the committed counter passes, which is the "
                              "figure that says how busy the vector ALUs are"})
