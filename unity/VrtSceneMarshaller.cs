@@ -29,6 +29,14 @@ public sealed class VrtSceneMarshaller
     int MaterialOf(Collider c)
     {
         var renderer = c.GetComponent<MeshRenderer>();
+        // WhittedTracer.cs:49 reads renderer.material, which on first access replaces the renderer's
+        // material by a private copy ("<name> (Instance)") and returns that.  sharedMaterial returns
+        // whatever the renderer holds now without copying: the asset while nothing has touched
+        // .material, the private copy afterwards, so a colour set through renderer.material.color
+        // by other scripts is seen here as well.  The values marshalled are the same; what differs
+        // is that collecting the scene does not instantiate a material per renderer, and that
+        // renderers sharing an asset share one entry of the material table.  Per-renderer
+        // MaterialPropertyBlock overrides are invisible to both properties.
         Material mat = renderer != null ? renderer.sharedMaterial : null;
         if (mat == null) mat = new Material(Shader.Find("Standard")) { name = "Missing", color = Color.red }; // WhittedTracer.cs:52
         if (_materialIndex.TryGetValue(mat, out int idx)) return idx;
