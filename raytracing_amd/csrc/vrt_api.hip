@@ -352,7 +352,10 @@ static int refresh_cam_pre(vrt_ctx* c, SceneBufs& sb)
 {
     if (!c->have_cam || sb.use_bvh) return VRT_OK;
     const DevScene& S = sb.scene;
-    std::vector<float4> pre((size_t)S.n_sph + S.n_box);
+    // layout: the spheres, padded to a multiple of four with entries no ray passes (the loop of
+    // intersect_brute takes four spheres per turn), then the boxes
+    const size_t n_sph4 = ((size_t)S.n_sph + 3) & ~(size_t)3;
+    std::vector<float4> pre(n_sph4 + S.n_box, make_float4(0.f, 0.f, 0.f, -INFINITY));
     const float ox = c->cam.ox, oy = c->cam.oy, oz = c->cam.oz;
     for (int i = 0; i < S.n_sph; ++i) {
         float4 s = sb.h_sph[i];
@@ -362,7 +365,7 @@ static int refresh_cam_pre(vrt_ctx* c, SceneBufs& sb)
     }
     for (int i = 0; i < S.n_box; ++i) {
         float4 b0 = sb.h_box[4 * (size_t)i];
-        pre[S.n_sph + i] = make_float4(ox - b0.x, oy - b0.y, oz - b0.z, 0.f);
+        pre[n_sph4 + i] = make_float4(ox - b0.x, oy - b0.y, oz - b0.z, 0.f);
     }
     if (pre.empty()) return VRT_OK;
     if (!sb.d_cam_pre) HIPCHK(c, hipMalloc(&sb.d_cam_pre, pre.size() * sizeof(float4)));
@@ -460,7 +463,12 @@ static int build_scene(vrt_ctx* c, const vrt_scene_desc* d, SceneBufs& sb)
         }
     }
 
-    HIPCHK(c, upload(&sb.d_sph, sph));
+    {   // padded to a multiple of four with spheres of infinite radius: |o - c|^2 - r^2 is -inf (or
+        // NaN), never > 0, so no ray passes them (intersect_brute tests four spheres per turn)
+        std::vector<float4> sph4 = sph;
+        sph4.resize((sph.size() + 3) & ~(size_t)3, make_float4(0.f, 0.f, 0.f, INFINITY));
+        HIPCHK(c, upload(&sb.d_sph, sph4));
+    }
     HIPCHK(c, upload(&sb.d_box, box));
     HIPCHK(c, upload(&sb.d_tri, tri));
     HIPCHK(c, upload(&sb.d_mat, mat));

@@ -32,12 +32,19 @@ namespace VRT_FORM {
 #ifndef VRT_BVH_WAVES
 #define VRT_BVH_WAVES 4
 #endif
-// The instantiations for simple brute-force scenes run at 5 waves per SIMD (96 VGPRs, two of them
-// spilled): the kernel issues a vector instruction in 44 % of the slots a SIMD has (a wave waits for
-// the scalar loads of the primitives and for its own dependent chains), and a fifth wave fills some of
-// them: teaching scene at 1080p 0.1111 -> 0.1009 ms; 6 waves (80 VGPRs, 29 spilled) 0.1022 ms.
+// The instantiations for simple brute-force scenes run at 6 waves per SIMD (80 VGPRs, six of them
+// spilled) and keep the pixel's sum between rounds in LDS like the tree kernels (VRT_KEEP_LDS_SIMPLE):
+// a wave of this kernel waits for the scalar loads of the primitives and for its own dependent chains,
+// and every further wave fills some of the gaps, until the scalar unit, which issues one instruction
+// per SIMD every four clocks and has 0.8 instructions to issue per vector instruction here, is the
+// busier of the two.  Teaching scene at 1080p: 4 waves 0.1111 ms, 5 waves 0.1009 ms, 5 waves with the
+// sum in LDS 0.0972 ms, 6 waves with the sum in LDS 0.0921 ms; 7 and 8 waves (with radiance and
+// throughput of the path in LDS as well, which costs 1.5 % by itself) 0.0919 / 0.0921 ms.
 #ifndef VRT_SIMPLE_WAVES
-#define VRT_SIMPLE_WAVES 5
+#define VRT_SIMPLE_WAVES 6
+#endif
+#ifndef VRT_KEEP_LDS_SIMPLE
+#define VRT_KEEP_LDS_SIMPLE 1
 #endif
 // SIMPLE (brute-force scenes only) is the instantiation for scenes of spheres and world-axis boxes
 // without triangles or textures, such as the shipped teaching scene: with those facts known at
@@ -87,7 +94,7 @@ __global__ __launch_bounds__(VRT_MEGA_THREADS, BVH ? VRT_BVH_WAVES : (SIMPLE ? V
     // and the pixel's sum waits in LDS while a round is traced: values that live across the tracing
     // code would otherwise be spilled to scratch memory by every wave, 6 KB each, which at 512 resident
     // waves per XCD is most of that XCD's L2 and ends up as gigabytes of write-backs per frame.
-    constexpr bool KEEP_LDS = BVH && VRT_KEEP_LDS;
+    constexpr bool KEEP_LDS = (BVH && VRT_KEEP_LDS) || (SIMPLE && VRT_KEEP_LDS_SIMPLE);
     int lane = threadIdx.x;
 #define VRT_PIXEL_OF_LANE()                                                        \
     DevParams Pl = P;   /* divisors hidden too: the invariant halves of divisions by them would be hoisted and kept */ \

@@ -342,12 +342,12 @@ __device__ __forceinline__ void test_prim(const DevScene& S, int id, f3 o, f3 d,
 #endif
 #define VRT_BRUTE_MAX 48
 #if VRT_LDS_PRIMS
-__shared__ float4 g_lds_sph[VRT_BRUTE_MAX], g_lds_aab[2 * VRT_BRUTE_MAX], g_lds_pre[VRT_BRUTE_MAX];
+__shared__ float4 g_lds_sph[VRT_BRUTE_MAX], g_lds_aab[2 * VRT_BRUTE_MAX], g_lds_pre[VRT_BRUTE_MAX + 4];
 __device__ __forceinline__ void stage_prims(const DevScene& S)
 {
-    for (int k = threadIdx.x; k < S.n_sph; k += blockDim.x) g_lds_sph[k] = S.sph[k];
+    for (int k = threadIdx.x; k < ((S.n_sph + 3) & ~3); k += blockDim.x) g_lds_sph[k] = S.sph[k];
     if (S.all_aab) for (int k = threadIdx.x; k < 2 * S.n_box; k += blockDim.x) g_lds_aab[k] = S.aab[k];
-    if (S.cam_pre) for (int k = threadIdx.x; k < S.n_sph + S.n_box; k += blockDim.x) g_lds_pre[k] = S.cam_pre[k];
+    if (S.cam_pre) for (int k = threadIdx.x; k < ((S.n_sph + 3) & ~3) + S.n_box; k += blockDim.x) g_lds_pre[k] = S.cam_pre[k];
     __syncthreads();
 }
 #define VRT_SPH(i) g_lds_sph[i]
@@ -365,25 +365,45 @@ __device__ __forceinline__ void stage_prims(const DevScene&) {}
 #ifndef VRT_AAB_CULL
 #define VRT_AAB_CULL 1
 #endif
+#ifndef VRT_SPH_GROUP
+#define VRT_SPH_GROUP 2   // 1, 2 or 4
+#endif
 template <bool CAM>
 __device__ __forceinline__ Hit intersect_brute(const DevScene& S, f3 o, f3 d, float maxd, float tlim, int skip, bool ANY)
 {
     Hit best; best.t = INFINITY; best.prim = -1; best.aux = 0;
     if (is_zero3(d)) return best;
-    for (int i = 0; i < S.n_sph; ++i) {
-        // hit_sphere / hit_sphere_pre in two steps: most spheres are missed by every ray of a wave
-        // (neighbouring pixels, or the occlusion rays of their hits), and the square root, which IEEE
-        // rounding makes 16 instructions, is only taken when some lane's ray passes the rejection test
-        float b, cc;
-        if (CAM) { const float4 pre = VRT_PRE(i); b = dot3(xyz(pre), d); cc = pre.w; }
-        else { const float4 sp = VRT_SPH(i); const f3 oc = o - xyz(sp); b = dot3(oc, d); cc = dot3(oc, oc) - sp.w * sp.w; }
-        const float disc = b * b - cc;
-        const bool pass = i != skip && cc > 0.f && b < 0.f && disc >= 0.f;
-        if (!__any(pass)) continue;
-        const float t = -b - sqrtf(disc);
-        if (pass && t >= 0.f && t <= maxd && t < best.t && t < tlim) {
-            best.t = t; best.prim = i;
-            if (ANY) return best;
+    // Spheres four at a time (the host pads the arrays to a multiple of four with spheres of infinite
+    // radius, which fail cc > 0 for every ray): the loop's scalar work - counter, address, load,
+    // wait, the lane-mask logic of the rejection test and its branch - is what this kernel is short
+    // of (the scalar unit issues one instruction per SIMD every four clocks), and it is paid once per
+    // group instead of once per sphere.
+    // hit_sphere / hit_sphere_pre in two steps: most spheres are missed by every ray of a wave
+    // (neighbouring pixels, or the occlusion rays of their hits), and the square root, which IEEE
+    // rounding makes 16 instructions, is only taken when some lane's ray passes the rejection test.
+    const int n_sph4 = (S.n_sph + 3) & ~3;
+    constexpr int G = VRT_SPH_GROUP;
+    for (int i = 0; i < n_sph4; i += G) {
+        float b[G], disc[G];
+        bool pass[G], some = false;
+#pragma unroll
+        for (int k = 0; k < G; ++k) {
+            float cc;
+            if (CAM) { const float4 pre = VRT_PRE(i + k); b[k] = dot3(xyz(pre), d); cc = pre.w; }
+            else { const float4 sp = VRT_SPH(i + k); const f3 oc = o - xyz(sp); b[k] = dot3(oc, d); cc = dot3(oc, oc) - sp.w * sp.w; }
+            disc[k] = b[k] * b[k] - cc;
+            pass[k] = i + k != skip && cc > 0.f && b[k] < 0.f && disc[k] >= 0.f;
+            some = some || pass[k];
+        }
+        if (!__any(some)) continue;
+#pragma unroll
+        for (int k = 0; k < G; ++k) {   // in id order: among equal distances the lowest id is kept
+            if (G > 1 && !__any(pass[k])) continue;
+            const float t = -b[k] - sqrtf(disc[k]);
+            if (pass[k] && t >= 0.f && t <= maxd && t < best.t && t < tlim) {
+                best.t = t; best.prim = i + k;
+                if (ANY) return best;
+            }
         }
     }
     if (S.all_aab) {
@@ -392,7 +412,7 @@ __device__ __forceinline__ Hit intersect_brute(const DevScene& S, f3 o, f3 d, fl
         for (int i = 0; i < S.n_box; ++i) {
             float t;
             const float4 a0 = VRT_AAB(2 * i), a1 = VRT_AAB(2 * i + 1);
-            const f3 p = CAM ? xyz(VRT_PRE(S.n_sph + i)) : o - xyz(a0);
+            const f3 p = CAM ? xyz(VRT_PRE(n_sph4 + i)) : o - xyz(a0);
 #if VRT_AAB_CULL
             float oo = dot3(p, p), bb = dot3(p, d);
             float cs = oo - a1.w, slack = 4e-6f * oo;
@@ -408,7 +428,7 @@ __device__ __forceinline__ Hit intersect_brute(const DevScene& S, f3 o, f3 d, fl
         if (!ANY && best.prim >= S.n_sph) {
             const int bi = best.prim - S.n_sph;
             const float4 a0 = S.aab[2 * bi], a1 = S.aab[2 * bi + 1];
-            const f3 p = CAM ? xyz(S.cam_pre[S.n_sph + bi]) : o - xyz(a0);
+            const f3 p = CAM ? xyz(S.cam_pre[n_sph4 + bi]) : o - xyz(a0);
             best.aux = aab_face(p, d, inv, a1.x, a1.y, a1.z, __float_as_int(a0.w));
         }
     } else {

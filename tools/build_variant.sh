@@ -6,7 +6,7 @@ root=$(cd "$(dirname "$0")/.." && pwd)
 src=$root/raytracing_amd/csrc
 tmp=/tmp/vrt_variant_$name
 mkdir -p $tmp
-flags="${VRT_OPT:--O3} -std=c++17 -fPIC -ffp-contract=off -fno-fast-math --offload-arch=gfx950 -Wno-unused-value $*"
+flags="${VRT_OPT:--O3} -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize --offload-arch=gfx950 -Wno-unused-value $*"
 pids=()
 for f in vrt_api vrt_kernels vrt_bvh vrt_wavefront vrt_blockwf vrt_multi; do
   /opt/rocm/bin/hipcc $flags -c $src/$f.hip -o $tmp/$f.o & pids+=($!)

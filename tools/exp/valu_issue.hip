@@ -4,7 +4,10 @@
 // wave's own stream); blocks are four waves (one per SIMD) and k blocks are kept resident per CU by
 // giving each 160 KiB / k of LDS, i.e. k waves per SIMD.  The program prints, per k, the wave
 // instructions issued per SIMD and nominal clock (chip-wide time x 2.4 GHz), with plain v_fma_f32,
-// with v_pk_fma_f32 and with a 50:50 mix of v_fma_f32 and v_xor_b32 (an integer filler).
+// with v_pk_fma_f32 and with a 50:50 mix of v_fma_f32 and v_xor_b32 (an integer filler); then the
+// same for scalar instructions (independent s_add_u32 chains) and for vector and scalar
+// instructions interleaved 1:1 and 2:1, which is what the render kernels' streams look like
+// (0.6 scalar instructions per vector instruction).
 //
 // build: hipcc -O2 --offload-arch=gfx950 tools/exp/valu_issue.hip -o tools/exp/valu_issue
 #include <hip/hip_runtime.h>
@@ -30,6 +33,9 @@ __global__ __launch_bounds__(256) void k_issue(float* out, int iters, float a, f
     int fill[N_CHAIN / 2];
 #pragma unroll
     for (int c = 0; c < N_CHAIN / 2; ++c) fill[c] = threadIdx.x + c;
+    unsigned sc[N_CHAIN];
+#pragma unroll
+    for (int c = 0; c < N_CHAIN; ++c) sc[c] = __builtin_amdgcn_readfirstlane(iters + c);
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
@@ -42,11 +48,27 @@ __global__ __launch_bounds__(256) void k_issue(float* out, int iters, float a, f
 #pragma unroll
                     for (int c = 0; c < N_CHAIN / 2; ++c)
                         asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[c]) : "v"(v2f{a, a}), "v"(v2f{b, b}));
-            } else {
+            } else if (KIND == 2) {
 #pragma unroll
                 for (int c = 0; c < N_CHAIN / 2; ++c) {
                     asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[c]) : "v"(a), "v"(b));
                     asm volatile("v_xor_b32 %0, %0, %1" : "+v"(fill[c]) : "v"(it));
+                }
+            } else if (KIND == 3) {   // scalar only
+#pragma unroll
+                for (int c = 0; c < N_CHAIN; ++c) asm volatile("s_add_u32 %0, %0, %1" : "+s"(sc[c]) : "s"(it) : "scc");
+            } else if (KIND == 4) {   // vector : scalar 1:1
+#pragma unroll
+                for (int c = 0; c < N_CHAIN / 2; ++c) {
+                    asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[c]) : "v"(a), "v"(b));
+                    asm volatile("s_add_u32 %0, %0, %1" : "+s"(sc[c]) : "s"(it) : "scc");
+                }
+            } else {                  // vector : scalar 2:1, 9 instructions per step counted as 8 + 1... see run()
+#pragma unroll
+                for (int c = 0; c < N_CHAIN / 2; ++c) {
+                    asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[2 * c]) : "v"(a), "v"(b));
+                    asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[2 * c + 1]) : "v"(a), "v"(b));
+                    asm volatile("s_add_u32 %0, %0, %1" : "+s"(sc[c]) : "s"(it) : "scc");
                 }
             }
         }
@@ -59,6 +81,8 @@ __global__ __launch_bounds__(256) void k_issue(float* out, int iters, float a, f
     int filler = 0;
 #pragma unroll
     for (int c = 0; c < N_CHAIN / 2; ++c) filler ^= fill[c];
+#pragma unroll
+    for (int c = 0; c < N_CHAIN; ++c) filler ^= (int)sc[c];
     if (s == 12345.678f || filler == -77) out[0] = s + g_dyn[0];   // keeps the chains alive, never true
 }
 
@@ -83,10 +107,11 @@ static void run(const char* name, int n_cu, float* d_out, double clock_hz)
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
             if (ms < best) best = ms;
         }
-        const double insts_per_wave = (double)iters * UNROLL * N_CHAIN;   // every kind issues N_CHAIN per unroll step
+        // kinds 0-4 issue N_CHAIN instructions per unroll step, kind 5 N_CHAIN vector + N_CHAIN / 2 scalar
+        const double insts_per_wave = (double)iters * UNROLL * (KIND == 5 ? N_CHAIN * 1.5 : N_CHAIN);
         const double waves_per_simd = k;
         const double cycles = best * 1e-3 * clock_hz;
-        printf("%-28s waves/SIMD %d  %.3f ms  wave-instr per SIMD-cycle %.3f  (cycles per wave-instr %.2f)\n", name, k, best,
+        printf("%-28s waves/SIMD %d  %.3f ms  instructions per SIMD-cycle %.3f  (cycles per instruction %.2f)\n", name, k, best,
                insts_per_wave * waves_per_simd / cycles, cycles / (insts_per_wave * waves_per_simd));
     }
 }
@@ -102,6 +127,9 @@ int main()
     run<0>("v_fma_f32", prop.multiProcessorCount, d_out, clock_hz);
     run<1>("v_pk_fma_f32", prop.multiProcessorCount, d_out, clock_hz);
     run<2>("v_fma_f32 + v_xor_b32 1:1", prop.multiProcessorCount, d_out, clock_hz);
+    run<3>("s_add_u32", prop.multiProcessorCount, d_out, clock_hz);
+    run<4>("v_fma_f32 + s_add_u32 1:1", prop.multiProcessorCount, d_out, clock_hz);
+    run<5>("v_fma_f32 + s_add_u32 2:1", prop.multiProcessorCount, d_out, clock_hz);
     CK(hipFree(d_out));
     return 0;
 }
