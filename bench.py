@@ -98,6 +98,10 @@ def algorithmic_flops(scene, rays, pixels):
 # (profiles/r03/valu_issue_probe.txt: 2.34-2.94 depending on the instruction mix).
 VALU_CLOCKS_MODEL = 2.0
 VALU_CLOCKS_MEASURED = 2.45
+# Clocks a SIMD needs per scalar instruction (s_add_u32 chains in the same probe: one per 4.2 clocks
+# with two or more waves resident, however many; scalar and vector instructions of different waves
+# overlap).  Branches and scalar loads are issued by the same unit.
+SALU_CLOCKS_MEASURED = 4.2
 
 
 def profiled_counters(workload, prefix="r03"):
@@ -109,7 +113,9 @@ def profiled_counters(workload, prefix="r03"):
     FP and integer instructions; one wave alone: 5.9; v_pk_fma_f32: 4.4), i.e. the 2 clocks per
     instruction of a SIMD-32 at the clock the chip holds under that load.  `valu_issue_frac` prices
     an instruction at the 2 clocks of the hardware model, `valu_issue_frac_of_measured_peak` at the
-    2.45 clocks the probe sustained."""
+    2.45 clocks the probe sustained.  `scalar_issue_frac_of_measured_peak` is the same for the scalar
+    side (scalar ALU, branch and scalar-memory instructions at the 4.2 clocks per instruction and SIMD
+    the probe measured): in these kernels it is the busier of the two units."""
     import csv
     for older in ("r02", "r01"):
         if os.path.exists(os.path.join(ROOT, "profiles", f"{prefix}_{workload}_pmc.csv")):
@@ -126,7 +132,12 @@ def profiled_counters(workload, prefix="r03"):
                 "valu_instructions_per_launch": insts,
                 "valu_issue_frac": insts * VALU_CLOCKS_MODEL / (1024 * 2.4e9 * avg_ns * 1e-9),
                 "valu_issue_frac_of_measured_peak": insts * VALU_CLOCKS_MEASURED / (1024 * 2.4e9 * avg_ns * 1e-9),
-                "lane_utilisation": lanes / (insts * 64.0)}
+                "lane_utilisation": lanes / (insts * 64.0),
+                "scalar_instructions_per_launch": (pmc.get("SQ_INSTS_SALU", 0.0) + pmc.get("SQ_INSTS_BRANCH", 0.0)
+                                                   + pmc.get("SQ_INSTS_SMEM", 0.0)),
+                "scalar_issue_frac_of_measured_peak":
+                    ((pmc.get("SQ_INSTS_SALU", 0.0) + pmc.get("SQ_INSTS_BRANCH", 0.0) + pmc.get("SQ_INSTS_SMEM", 0.0))
+                     * SALU_CLOCKS_MEASURED / (1024 * 2.4e9 * avg_ns * 1e-9))}
     except Exception:
         return None
 

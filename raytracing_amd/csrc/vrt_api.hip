@@ -353,7 +353,7 @@ static int refresh_cam_pre(vrt_ctx* c, SceneBufs& sb)
     if (!c->have_cam || sb.use_bvh) return VRT_OK;
     const DevScene& S = sb.scene;
     // layout: the spheres, padded to a multiple of four with entries no ray passes (the loop of
-    // intersect_brute takes four spheres per turn), then the boxes
+    // intersect_brute takes a group of spheres per turn), then the boxes
     const size_t n_sph4 = ((size_t)S.n_sph + 3) & ~(size_t)3;
     std::vector<float4> pre(n_sph4 + S.n_box, make_float4(0.f, 0.f, 0.f, -INFINITY));
     const float ox = c->cam.ox, oy = c->cam.oy, oz = c->cam.oz;
@@ -464,7 +464,7 @@ static int build_scene(vrt_ctx* c, const vrt_scene_desc* d, SceneBufs& sb)
     }
 
     {   // padded to a multiple of four with spheres of infinite radius: |o - c|^2 - r^2 is -inf (or
-        // NaN), never > 0, so no ray passes them (intersect_brute tests four spheres per turn)
+        // NaN), never > 0, so no ray passes them (intersect_brute tests a group of spheres per turn)
         std::vector<float4> sph4 = sph;
         sph4.resize((sph.size() + 3) & ~(size_t)3, make_float4(0.f, 0.f, 0.f, INFINITY));
         HIPCHK(c, upload(&sb.d_sph, sph4));

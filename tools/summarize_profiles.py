@@ -32,10 +32,21 @@ def dominant(acc):
     return best
 
 
+def newest_per_dir(files):
+    """A pass run again into the same directory leaves the earlier run's file (named by process id)
+    beside the new one: only the newest file of each directory counts."""
+    by_dir = {}
+    for f in files:
+        d = os.path.dirname(f)
+        if d not in by_dir or os.path.getmtime(f) > os.path.getmtime(by_dir[d]):
+            by_dir[d] = f
+    return sorted(by_dir.values())
+
+
 for bench in sorted(glob.glob(os.path.join(src, "bench_*.json"))):
     wl = os.path.basename(bench)[6:-5]
     shutil.copy(bench, os.path.join(dst, f"{prefix}_bench_{wl}.json"))
-    stats = glob.glob(os.path.join(src, f"trace_{wl}", "**", "*kernel_stats.csv"), recursive=True)
+    stats = newest_per_dir(glob.glob(os.path.join(src, f"trace_{wl}", "**", "*kernel_stats.csv"), recursive=True))
     if stats:
         rows = list(csv.DictReader(open(stats[0])))
         with open(os.path.join(dst, f"{prefix}_{wl}_kernel_stats.csv"), "w", newline="") as f:
@@ -44,8 +55,8 @@ for bench in sorted(glob.glob(os.path.join(src, "bench_*.json"))):
             for r in rows[:12]:
                 w.writerow(r)
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
-    for f in glob.glob(os.path.join(src, f"pmc_{wl}_*", "**", "*counter_collection.csv"), recursive=True) + \
-            glob.glob(os.path.join(src, f"sq_{wl}", "**", "*counter_collection.csv"), recursive=True):
+    for f in newest_per_dir(glob.glob(os.path.join(src, f"pmc_{wl}_*", "**", "*counter_collection.csv"), recursive=True) +
+                            glob.glob(os.path.join(src, f"sq_{wl}", "**", "*counter_collection.csv"), recursive=True)):
         for r in csv.DictReader(open(f)):
             acc[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     kern = dominant(acc)
