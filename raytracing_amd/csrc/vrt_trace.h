@@ -317,7 +317,9 @@ struct Hit {
 };
 
 // Tests primitive `id` and keeps it if it beats `best` by (t, id).
-__device__ __forceinline__ void test_prim(const DevScene& S, int id, f3 o, f3 d, float maxd, Hit& best)
+// (skip: the primitive the ray was spawned on is tested like any other and refused here, which is one
+// region of exec-mask instructions less than a test around the call)
+__device__ __forceinline__ void test_prim(const DevScene& S, int id, f3 o, f3 d, float maxd, Hit& best, int skip = -1)
 {
     float t; int aux = 0; bool h;
     if (id < S.n_sph) {
@@ -329,7 +331,7 @@ __device__ __forceinline__ void test_prim(const DevScene& S, int id, f3 o, f3 d,
         const float4* tr = S.tri + 3 * (size_t)(id - S.n_sph - S.n_box);
         h = hit_tri(xyz(ldc(tr)), xyz(ldc(tr + 1)), xyz(ldc(tr + 2)), o, d, maxd, t);
     }
-    if (h && (t < best.t || (t == best.t && id < best.prim) || best.prim < 0)) {
+    if (h && id != skip && (t < best.t || (t == best.t && id < best.prim) || best.prim < 0)) {
         best.t = t; best.prim = id; best.aux = aux;
     }
 }
@@ -495,12 +497,15 @@ __device__ __forceinline__ bool slab_test(f3 lo, f3 hi, f3 o, f3 inv, float tmax
 #ifndef VRT_CC_EARLY
 #define VRT_CC_EARLY 1
 #endif
-// VRT_PUSH_BRANCHLESS (study; 1: any-hit traversals, 2: closest-hit ones as well): trav_inner leaves
+// VRT_PUSH_BRANCHLESS (1: any-hit traversals, 2: closest-hit ones as well): trav_inner leaves
 // its children on the stack without branches; every push is a store, and the stores that are not to
-// happen go to a row past the stack (one more row of LDS).  Fewer scalar mask instructions, but
-// measured slower on MI355X (10k spheres 24.6 -> 25.1 / 25.0 ms, 1M triangles 2.07 -> 2.10 / 2.07 ms); off.
+// happen go to a row past the stack (one more row of LDS).  Fewer exec-mask instructions and
+// branches for more vector and LDS instructions.  Slower while the compiler's packed arithmetic kept
+// the vector side busy with moves (10k spheres 24.6 -> 25.1 / 25.0 ms); since the scalar unit is the
+// busier one, form 1 wins: 10k spheres 23.50 -> 23.21 ms, 1M triangles 1.935 -> 1.927 ms (form 2:
+// 23.56 / 1.950 ms).
 #ifndef VRT_PUSH_BRANCHLESS
-#define VRT_PUSH_BRANCHLESS 0
+#define VRT_PUSH_BRANCHLESS 1
 #endif
 __shared__ unsigned long long g_lds_stack[(VRT_TRAV_STACK + (VRT_PUSH_BRANCHLESS ? 1 : 0)) * VRT_STACK_LANES];
 
@@ -741,7 +746,7 @@ __device__ __forceinline__ bool trav_leaf(const DevScene& S, Trav& T, bool any, 
 {
     const int id = ~T.node;
     count_lanes(S, 7, counted);
-    if (id != T.skip) test_prim(S, id, T.o, T.d, T.maxd, T.best);
+    test_prim(S, id, T.o, T.d, T.maxd, T.best, T.skip);
     if (any && T.best.prim >= 0) {
         if (T.best.t < T.tlim) return true;
         T.best.prim = -1; T.best.t = INFINITY;
