@@ -317,6 +317,9 @@ struct Hit {
 };
 
 // Tests primitive `id` and keeps it if it beats `best` by (t, id).
+#ifndef VRT_KEY_ACCEPT
+#define VRT_KEY_ACCEPT 1
+#endif
 // (skip: the primitive the ray was spawned on is tested like any other and refused here, which is one
 // region of exec-mask instructions less than a test around the call)
 __device__ __forceinline__ void test_prim(const DevScene& S, int id, f3 o, f3 d, float maxd, Hit& best, int skip = -1)
@@ -331,9 +334,21 @@ __device__ __forceinline__ void test_prim(const DevScene& S, int id, f3 o, f3 d,
         const float4* tr = S.tri + 3 * (size_t)(id - S.n_sph - S.n_box);
         h = hit_tri(xyz(ldc(tr)), xyz(ldc(tr + 1)), xyz(ldc(tr + 2)), o, d, maxd, t);
     }
+#if VRT_KEY_ACCEPT
+    // (t, id) against (best.t, best.prim) as one 64-bit unsigned comparison instead of five float and
+    // integer comparisons joined on the scalar unit: distances of hits are >= 0 and not NaN, so they
+    // order like their bit patterns once -0 is made +0 (x + 0); "no hit yet" is (+inf, -1), the
+    // largest key there is, and best.prim < 0 never occurs with another distance.
+    if (h && id != skip) {
+        const unsigned long long key = ((unsigned long long)__float_as_uint(t + 0.f) << 32) | (unsigned)id;
+        const unsigned long long bkey = ((unsigned long long)__float_as_uint(best.t + 0.f) << 32) | (unsigned)best.prim;
+        if (key < bkey) { best.t = t; best.prim = id; best.aux = aux; }
+    }
+#else
     if (h && id != skip && (t < best.t || (t == best.t && id < best.prim) || best.prim < 0)) {
         best.t = t; best.prim = id; best.aux = aux;
     }
+#endif
 }
 
 // Brute force over all primitives in id order.  Primitive data is wave-uniform, so the loads go
@@ -645,12 +660,21 @@ __device__ __forceinline__ Slab4 slab4_signed(float4 nx, float4 ny, float4 nz, f
 
 __device__ __forceinline__ void trav_push(const DevScene& S, Trav& T, unsigned long long* my_lds, float tnear, int code)
 {
+#if VRT_PUSH_BRANCHLESS
+    // no branch on "is there room": an entry that does not fit is written to the row past the stack
+    // and dropped; the query is then finished by trav_stackless()
+    const bool room = T.sp < S.stack_cap;   // VRT_TRAV_STACK unless a test shortens it
+    my_lds[(room ? T.sp : VRT_TRAV_STACK) * VRT_STACK_LANES] = ((unsigned long long)__float_as_uint(tnear) << 32) | (unsigned)code;
+    T.sp += room ? 1 : 0;
+    T.ovf = T.ovf || !room;
+#else
     if (T.sp < S.stack_cap) {   // VRT_TRAV_STACK unless a test shortens it
         my_lds[T.sp * VRT_STACK_LANES] = ((unsigned long long)__float_as_uint(tnear) << 32) | (unsigned)code;
         T.sp++;
     } else {
         T.ovf = true;   // dropped: the query is finished by trav_stackless()
     }
+#endif
 }
 
 // The same push without a branch: `valid` says whether there is an entry at all.  An entry that is
