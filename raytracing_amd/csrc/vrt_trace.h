@@ -522,6 +522,12 @@ __device__ __forceinline__ bool slab_test(f3 lo, f3 hi, f3 o, f3 inv, float tmax
 #ifndef VRT_PUSH_BRANCHLESS
 #define VRT_PUSH_BRANCHLESS 1
 #endif
+// What T.node holds when there is nothing to enter: the code of an unused child slot, which no
+// traversal ever enters or pushes.
+#define VRT_NODE_NONE ((int)0x80000000)
+#ifndef VRT_TRAV_VALUE_FLOW
+#define VRT_TRAV_VALUE_FLOW 1
+#endif
 __shared__ unsigned long long g_lds_stack[(VRT_TRAV_STACK + (VRT_PUSH_BRANCHLESS ? 1 : 0)) * VRT_STACK_LANES];
 
 // Orders two (tnear, code) candidates, nearer first.
@@ -556,7 +562,8 @@ struct Trav {
     Hit best;
     int node;               // what to look at next: >= 0 inner node, < 0 leaf ~primitive
     int sp;                 // entries on the lane's stack
-    bool ovf;               // an entry did not fit the stack and was dropped
+    int ovf;                // entries that did not fit the stack and were dropped (a count, not a flag: a flag
+                            // that lives across divergent branches is kept as a lane mask and merged on the scalar unit)
 };
 
 __device__ __forceinline__ void trav_begin(Trav& T, f3 o, f3 d, float maxd, float tlim, int skip)
@@ -574,7 +581,7 @@ __device__ __forceinline__ void trav_begin(Trav& T, f3 o, f3 d, float maxd, floa
 #endif
     T.maxd = maxd; T.tlim = tlim; T.lim0 = fminf(maxd, tlim); T.skip = skip;
     T.best.t = INFINITY; T.best.prim = -1; T.best.aux = 0;
-    T.node = 0; T.sp = 0; T.ovf = false;
+    T.node = 0; T.sp = 0; T.ovf = 0;
 }
 
 // Distance beyond which nothing can matter to the query any more.
@@ -666,13 +673,13 @@ __device__ __forceinline__ void trav_push(const DevScene& S, Trav& T, unsigned l
     const bool room = T.sp < S.stack_cap;   // VRT_TRAV_STACK unless a test shortens it
     my_lds[(room ? T.sp : VRT_TRAV_STACK) * VRT_STACK_LANES] = ((unsigned long long)__float_as_uint(tnear) << 32) | (unsigned)code;
     T.sp += room ? 1 : 0;
-    T.ovf = T.ovf || !room;
+    T.ovf += room ? 0 : 1;
 #else
     if (T.sp < S.stack_cap) {   // VRT_TRAV_STACK unless a test shortens it
         my_lds[T.sp * VRT_STACK_LANES] = ((unsigned long long)__float_as_uint(tnear) << 32) | (unsigned)code;
         T.sp++;
     } else {
-        T.ovf = true;   // dropped: the query is finished by trav_stackless()
+        T.ovf = 1;   // dropped: the query is finished by trav_stackless()
     }
 #endif
 }
@@ -686,14 +693,15 @@ __device__ __forceinline__ void trav_push_if(int cap, Trav& T, unsigned long lon
     const bool store = valid && T.sp < cap;
     const int row = store ? T.sp : VRT_TRAV_STACK;
     my_lds[row * VRT_STACK_LANES] = ((unsigned long long)__float_as_uint(tnear) << 32) | (unsigned)code;
-    T.ovf = T.ovf || (valid && !store);
+    T.ovf += (valid && !store) ? 1 : 0;
     T.sp += store ? 1 : 0;
 }
 
 // Inner-node step of the per-lane traversal of the 4-wide tree: loads the node T.node, tests its
 // four child boxes, enters the nearest hit child and leaves the others on the stack as
 // (tnear, code) pairs (an any-hit query enters the first hit child and keeps the others with
-// distance 0).  Returns true when no child was hit, i.e. the caller has to pop.
+// distance 0).  Returns true when no child was hit, i.e. the caller has to pop; T.node is then
+// VRT_NODE_NONE.
 __device__ __forceinline__ bool trav_inner(const DevScene& S, Trav& T, unsigned long long* my_lds, bool any)
 {
     count_lanes(S, 6);
@@ -730,7 +738,7 @@ __device__ __forceinline__ bool trav_inner(const DevScene& S, Trav& T, unsigned 
         // the first hit child is entered, the hit children after it wait with distance 0, in child order
         const int cap = S.stack_cap;
         const bool b1 = r.h0, b2 = b1 || r.h1, b3 = b2 || r.h2, some = b3 || r.h3;
-        T.node = r.h0 ? c0 : r.h1 ? c1 : r.h2 ? c2 : r.h3 ? c3 : T.node;
+        T.node = r.h0 ? c0 : r.h1 ? c1 : r.h2 ? c2 : r.h3 ? c3 : VRT_NODE_NONE;
         trav_push_if(cap, T, my_lds, r.h1 && b1, 0.f, c1);
         trav_push_if(cap, T, my_lds, r.h2 && b2, 0.f, c2);
         trav_push_if(cap, T, my_lds, r.h3 && b3, 0.f, c3);
@@ -740,6 +748,7 @@ __device__ __forceinline__ bool trav_inner(const DevScene& S, Trav& T, unsigned 
 #define VRT_VISIT_ANY(H, C) if (H) { if (!taken) { T.node = C; taken = true; } else trav_push(S, T, my_lds, 0.f, C); }
         VRT_VISIT_ANY(r.h0, c0) VRT_VISIT_ANY(r.h1, c1) VRT_VISIT_ANY(r.h2, c2) VRT_VISIT_ANY(r.h3, c3)
 #undef VRT_VISIT_ANY
+        if (!taken) T.node = VRT_NODE_NONE;
         return !taken;
 #endif
     }
@@ -756,12 +765,22 @@ __device__ __forceinline__ bool trav_inner(const DevScene& S, Trav& T, unsigned 
     trav_push_if(cap, T, my_lds, t1 < INFINITY, t1, c1);
     return !some;
 #else
-    if (!(t0 < INFINITY)) return true;
+#if VRT_TRAV_VALUE_FLOW
+    // no exit for "no child hit": t1..t3 are infinite too when t0 is, so nothing is pushed then
+    const bool some = t0 < INFINITY;
+    T.node = some ? c0 : VRT_NODE_NONE;
+    if (t3 < INFINITY) trav_push(S, T, my_lds, t3, c3);
+    if (t2 < INFINITY) trav_push(S, T, my_lds, t2, c2);
+    if (t1 < INFINITY) trav_push(S, T, my_lds, t1, c1);
+    return !some;
+#else
+    if (!(t0 < INFINITY)) { T.node = VRT_NODE_NONE; return true; }
     T.node = c0;
     if (t3 < INFINITY) trav_push(S, T, my_lds, t3, c3);
     if (t2 < INFINITY) trav_push(S, T, my_lds, t2, c2);
     if (t1 < INFINITY) trav_push(S, T, my_lds, t1, c1);
     return false;
+#endif
 #endif
 }
 
@@ -857,6 +876,35 @@ __device__ __forceinline__ void intersect_bvh4_tree(const DevScene& S, Trav& T, 
 {
     unsigned long long* my_lds = g_lds_stack + threadIdx.x;
     if (packet && intersect_bvh4_packet(S, T, true, any)) return;
+#if VRT_TRAV_VALUE_FLOW
+    // The state of the walk is carried in vector registers only: T.node is the next thing to look at
+    // or VRT_NODE_NONE ("take the next entry off the stack"; with an empty stack: done), an any-hit
+    // query that has its answer empties its stack, and the entry a pop settles on is a value, not a
+    // flag.  Flags that live across divergent branches (pop / found / overflowed) are lane masks in
+    // scalar registers, and every merge of one is two or three instructions on the scalar unit, the
+    // busier unit of these kernels.
+    // every node is entered at most once; the bound only guards against a corrupt tree
+    for (int guard = 2 * S.n_prims + 8; guard > 0 && T.node != VRT_NODE_NONE; --guard) {
+        if (T.node >= 0) {
+            trav_inner(S, T, my_lds, any);
+        } else {
+            const bool done = trav_leaf(S, T, any);
+            T.node = VRT_NODE_NONE;
+            T.sp = done ? 0 : T.sp;
+            T.ovf = done ? 0 : T.ovf;
+        }
+        if (T.node == VRT_NODE_NONE && T.sp > 0) {
+            const float lim = trav_limit(T);
+            int cand;
+            do {
+                --T.sp;
+                const unsigned long long e = my_lds[T.sp * VRT_STACK_LANES];
+                cand = !(__uint_as_float((unsigned)(e >> 32)) > lim) ? (int)(unsigned)e : VRT_NODE_NONE;
+            } while (cand == VRT_NODE_NONE && T.sp > 0);
+            T.node = cand;
+        }
+    }
+#else
     // every node is entered at most once; the bound only guards against a corrupt tree
     for (int guard = 2 * S.n_prims + 8; guard > 0; --guard) {
         bool pop;
@@ -864,6 +912,7 @@ __device__ __forceinline__ void intersect_bvh4_tree(const DevScene& S, Trav& T, 
         else { if (trav_leaf(S, T, any)) return; pop = true; }
         if (pop && !trav_pop(T, my_lds)) break;
     }
+#endif
     if (T.ovf) trav_stackless(S, T, any);
 }
 
@@ -1305,7 +1354,7 @@ __device__ __forceinline__ bool quad_inner(const DevScene& S, Trav& T, int c, in
         if (e < 4 * S.stack_cap) *quad_slot(qcol, e) = ((unsigned long long)__float_as_uint(t0) << 32) | (unsigned)code;
     }
     T.sp += n_push;
-    if (T.sp > 4 * S.stack_cap) { T.sp = 4 * S.stack_cap; T.ovf = true; }   // finished by trav_stackless()
+    if (T.sp > 4 * S.stack_cap) { T.sp = 4 * S.stack_cap; T.ovf = 1; }   // finished by trav_stackless()
     T.node = (int)next;
     return false;
 }
