@@ -386,6 +386,9 @@ __device__ __forceinline__ void stage_prims(const DevScene&) {}
 #ifndef VRT_AAB_CULL
 #define VRT_AAB_CULL 1
 #endif
+#ifndef VRT_ANY_UNIFORM_EXIT
+#define VRT_ANY_UNIFORM_EXIT 1
+#endif
 #ifndef VRT_SPH_GROUP
 #define VRT_SPH_GROUP 2   // 1, 2 or 4
 #endif
@@ -394,8 +397,8 @@ __device__ __forceinline__ Hit intersect_brute(const DevScene& S, f3 o, f3 d, fl
 {
     Hit best; best.t = INFINITY; best.prim = -1; best.aux = 0;
     if (is_zero3(d)) return best;
-    // Spheres four at a time (the host pads the arrays to a multiple of four with spheres of infinite
-    // radius, which fail cc > 0 for every ray): the loop's scalar work - counter, address, load,
+    // Spheres in groups of VRT_SPH_GROUP (the host pads the arrays to a multiple of four with spheres of
+    // infinite radius, which fail cc > 0 for every ray): the loop's scalar work - counter, address, load,
     // wait, the lane-mask logic of the rejection test and its branch - is what this kernel is short
     // of (the scalar unit issues one instruction per SIMD every four clocks), and it is paid once per
     // group instead of once per sphere.
@@ -421,11 +424,21 @@ __device__ __forceinline__ Hit intersect_brute(const DevScene& S, f3 o, f3 d, fl
         for (int k = 0; k < G; ++k) {   // in id order: among equal distances the lowest id is kept
             if (G > 1 && !__any(pass[k])) continue;
             const float t = -b[k] - sqrtf(disc[k]);
+#if VRT_ANY_UNIFORM_EXIT
+            // an occlusion query keeps its first hit and rides along until every lane of the wave has
+            // one (a lane that leaves a loop on its own costs the loop exec-mask bookkeeping every turn)
+            if (pass[k] && t >= 0.f && t <= maxd && t < best.t && t < tlim && (!ANY || best.prim < 0)) {
+                best.t = t; best.prim = i + k;
+            }
+        }
+        if (ANY && !__any(best.prim < 0)) return best;
+#else
             if (pass[k] && t >= 0.f && t <= maxd && t < best.t && t < tlim) {
                 best.t = t; best.prim = i + k;
                 if (ANY) return best;
             }
         }
+#endif
     }
     if (S.all_aab) {
         // every box is aligned with the world axes: one reciprocal per ray component serves all
@@ -442,10 +455,17 @@ __device__ __forceinline__ Hit intersect_brute(const DevScene& S, f3 o, f3 d, fl
             bool may = !((bb * bb - cs + slack < 0.f) || (cs > slack && bb > 0.f));
             if (!__any(may)) continue;
 #endif
+#if VRT_ANY_UNIFORM_EXIT
+            if (i + S.n_sph != skip && (!ANY || best.prim < 0) && aab_slabs(p, d, inv, a1.x, a1.y, a1.z, maxd, t) && t < best.t && t < tlim) {
+                best.t = t; best.prim = i + S.n_sph;
+            }
+            if (ANY && !__any(best.prim < 0)) return best;
+#else
             if (i + S.n_sph != skip && aab_slabs(p, d, inv, a1.x, a1.y, a1.z, maxd, t) && t < best.t && t < tlim) {
                 best.t = t; best.prim = i + S.n_sph;
                 if (ANY) return best;
             }
+#endif
         }
         // the entry face of the closest box, once per query instead of once per box tested
         if (!ANY && best.prim >= S.n_sph) {
