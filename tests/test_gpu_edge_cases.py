@@ -197,3 +197,31 @@ def test_small_tree_with_rays_in_every_direction(vrt_ctx, vrt_opts, oracle_mod, 
             _cmp(vrt_ctx, oracle_mod, s, cam, ra.Params(spp=4, offsets=offs, seed=1, max_depth=4, flags=flags))
     vrt_opts("sample_shift", 0)   # 8x8-pixel waves with four samples looped per lane
     _cmp(vrt_ctx, oracle_mod, s, cam, ra.Params(spp=4, offsets=offs, seed=1, max_depth=4, flags=abi.VRT_FIX_AO_BASIS))
+
+
+@pytest.mark.parametrize("n_spheres", [0, 1, 2, 3, 4, 5, 8, 9])
+@pytest.mark.parametrize("n_boxes", [0, 1, 2])
+def test_brute_force_loop_at_every_group_remainder(vrt_ctx, oracle_mod, n_spheres, n_boxes):
+    """The brute-force loop takes its spheres in groups and the library pads the sphere arrays with
+    spheres no ray can hit: every remainder of the group size, with and without boxes behind them
+    (whose camera terms sit after the padded spheres), mirrors and a shadow-casting point light so
+    that occlusion queries, bounces from spheres and from boxes and the skip id are all in play."""
+    if n_spheres == 0 and n_boxes == 0:
+        pytest.skip("an empty scene is refused")
+    rng = np.random.default_rng(100 * n_spheres + n_boxes)
+    s = ra.Scene()
+    metal = s.add_material("Metal", abi.VRT_MAT_METAL, (0.9, 0.9, 0.9))
+    red = s.add_material("Red", abi.VRT_MAT_SOLID, (0.9, 0.2, 0.2))
+    wood = s.add_material("Wood", abi.VRT_MAT_SOLID, (0.6, 0.4, 0.2))
+    for k in range(n_spheres):
+        c = (float(rng.uniform(-1.8, 1.8)), float(rng.uniform(0.4, 2.2)), float(rng.uniform(-1.0, 2.0)))
+        s.add_sphere(c, float(rng.uniform(0.25, 0.6)), metal if k % 2 == 0 else red)
+    if n_boxes >= 1:
+        s.add_box((0.0, -0.1, 0.5), (3.0, 0.1, 3.0), wood)
+    if n_boxes >= 2:
+        s.add_box((1.2, 0.5, 1.5), (0.4, 0.5, 0.4), metal)
+    s.add_light(abi.VRT_LIGHT_POINT, (1.0, 4.0, -2.0), ls=1.0, cast_shadows=True)
+    s.add_light(abi.VRT_LIGHT_DIRECTIONAL, (0.3, -1.0, 0.2), ls=0.5, cast_shadows=False)
+    rgba, hit, st = _cmp(vrt_ctx, oracle_mod, s, _cam(96, 72), ra.Params(spp=1, max_depth=5))
+    assert st.bvh_nodes == 0
+    assert hit.max() < n_spheres + n_boxes
