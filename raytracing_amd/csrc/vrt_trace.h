@@ -475,6 +475,9 @@ __device__ __forceinline__ Hit intersect_brute(const DevScene& S, f3 o, f3 d, fl
             best.aux = aab_face(p, d, inv, a1.x, a1.y, a1.z, __float_as_int(a0.w));
         }
     } else {
+#if VRT_ANY_UNIFORM_EXIT
+        if (ANY && best.prim >= 0) return best;   // answered among the spheres: the first hit in id order stands
+#endif
         for (int i = 0; i < S.n_box; ++i) {
             float t; int aux;
             const float4* b = S.box + 4 * i;
@@ -493,6 +496,9 @@ __device__ __forceinline__ Hit intersect_brute(const DevScene& S, f3 o, f3 d, fl
             }
         }
     }
+#if VRT_ANY_UNIFORM_EXIT
+    if (ANY && best.prim >= 0) return best;   // answered among the spheres or boxes
+#endif
     for (int i = 0; i < S.n_tri; ++i) {
         float t;
         const float4* tr = S.tri + 3 * (size_t)i;

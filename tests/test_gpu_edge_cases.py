@@ -225,3 +225,4 @@ def test_brute_force_loop_at_every_group_remainder(vrt_ctx, oracle_mod, n_sphere
     rgba, hit, st = _cmp(vrt_ctx, oracle_mod, s, _cam(96, 72), ra.Params(spp=1, max_depth=5))
     assert st.bvh_nodes == 0
     assert hit.max() < n_spheres + n_boxes
+
