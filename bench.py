@@ -578,8 +578,10 @@ def main():
                     "kernel_ms": kernel_ms, "algorithmic_flops_per_launch": flops,
                     "framebuffer_bytes_per_launch": fb_bytes,
                     "hbm_achieved_GBps": fb_bytes / (kernel_ms * 1e-3) / 1e9,
-                    "note": "FP32 vector-ALU bound (no dense contraction, primitives in scalar registers); "
-                            "peak is the MI355X FP32 vector rate"}
+                    "note": "instruction-issue bound, neither HBM nor MFMA (no dense contraction, primitives in "
+                            "scalar registers): achieved / peak prices the arithmetic of the intersection tests and "
+                            "of shading against the MI355X FP32 vector rate; `profiled` holds the measured shares of "
+                            "the vector and of the scalar issue rate of a SIMD (the scalar unit is the busier one)"}
         else:
             roof = tree_roofline(args.workload, scene, st, rays, my_queries, kernel_ms, fb_bytes)
         prof = profiled_counters(args.workload)
