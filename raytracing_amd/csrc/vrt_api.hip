@@ -262,7 +262,9 @@ extern "C" int vrt_host_alloc(vrt_ctx* c, uint64_t bytes, void** out)
     *out = nullptr;
     HIPCHK(c, hipSetDevice(c->device));
     void* p = nullptr;
-    HIPCHK(c, hipHostMalloc(&p, (size_t)bytes, hipHostMallocDefault));
+    // a buffer of a multi-GPU context is stored to by the frame kernels of all its GPUs: asked for as
+    // portable and mapped explicitly, although the runtime maps page-locked memory for every device
+    HIPCHK(c, hipHostMalloc(&p, (size_t)bytes, c->multi ? (hipHostMallocPortable | hipHostMallocMapped) : hipHostMallocDefault));
     c->host_allocs.push_back(p);
     c->host_alloc_bytes.push_back((size_t)bytes);
     *out = p;
