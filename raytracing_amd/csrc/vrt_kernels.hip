@@ -89,11 +89,13 @@ __global__ __launch_bounds__(VRT_MEGA_THREADS, BVH ? VRT_BVH_WAVES : (SIMPLE ? V
     const int n_sl = 1 << shift;                       // sample lanes per pixel
     const int pshift = 6 - shift;                      // log2(pixels per wave)
     const int pw_shift = (pshift + 1) >> 1;            // tile width 2^ceil(pshift/2), height 2^floor(pshift/2)
-    // Tree kernels (KEEP_LDS): what a lane knows about its pixel is worked out again where it is needed
-    // (per round, and for the store at the end) from a lane number the compiler cannot see through,
-    // and the pixel's sum waits in LDS while a round is traced: values that live across the tracing
-    // code would otherwise be spilled to scratch memory by every wave, 6 KB each, which at 512 resident
-    // waves per XCD is most of that XCD's L2 and ends up as gigabytes of write-backs per frame.
+    // Tree kernels and the kernels for simple scenes (KEEP_LDS): what a lane knows about its pixel is
+    // worked out again where it is needed (per round, and for the store at the end) from a lane number
+    // the compiler cannot see through, and the pixel's sum waits in LDS while a round is traced.  In
+    // the tree kernels values that live across the tracing code would otherwise be spilled to scratch
+    // memory by every wave, 6 KB each, which at 512 resident waves per XCD is most of that XCD's L2
+    // and ends up as gigabytes of write-backs per frame; in the kernels for simple scenes the
+    // registers saved are what lets a sixth wave per SIMD in.
     constexpr bool KEEP_LDS = (BVH && VRT_KEEP_LDS) || (SIMPLE && VRT_KEEP_LDS_SIMPLE);
     int lane = threadIdx.x;
 #define VRT_PIXEL_OF_LANE()                                                        \
