@@ -1107,6 +1107,32 @@ __device__ __forceinline__ float wave_max_f(float v)
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 #undef VRT_WAVE_REDUCE
+// Minimum and maximum of three values at once: the six reductions take their steps in turn, so the
+// five instructions between two steps of one reduction are the wait states its DPP read needs, and
+// no s_nop stands between them (13 of a reduction's 19 issue slots are s_nop when it runs alone).
+#define VRT_STEP6(CTRL)                                            \
+    "v_min_f32_dpp %0, %0, %0 " CTRL "\n\tv_max_f32_dpp %1, %1, %1 " CTRL "\n\t" \
+    "v_min_f32_dpp %2, %2, %2 " CTRL "\n\tv_max_f32_dpp %3, %3, %3 " CTRL "\n\t" \
+    "v_min_f32_dpp %4, %4, %4 " CTRL "\n\tv_max_f32_dpp %5, %5, %5 " CTRL "\n\t"
+__device__ __forceinline__ void wave_minmax3(float& a_lo, float& a_hi, float& b_lo, float& b_hi, float& c_lo, float& c_hi)
+{
+    asm("s_nop 1\n\t"
+        VRT_STEP6("row_shr:1 row_mask:0xf bank_mask:0xf")
+        VRT_STEP6("row_shr:2 row_mask:0xf bank_mask:0xf")
+        VRT_STEP6("row_shr:4 row_mask:0xf bank_mask:0xf")
+        VRT_STEP6("row_shr:8 row_mask:0xf bank_mask:0xf")
+        VRT_STEP6("row_bcast:15 row_mask:0xa bank_mask:0xf")
+        VRT_STEP6("row_bcast:31 row_mask:0xc bank_mask:0xf")
+        "s_nop 1"
+        : "+v"(a_lo), "+v"(a_hi), "+v"(b_lo), "+v"(b_hi), "+v"(c_lo), "+v"(c_hi));
+    a_lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a_lo), 63));
+    a_hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a_hi), 63));
+    b_lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b_lo), 63));
+    b_hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b_hi), 63));
+    c_lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c_lo), 63));
+    c_hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c_hi), 63));
+}
+#undef VRT_STEP6
 
 // The collection pass.  Not inlined on purpose: compiled into the frame kernel it changed the
 // register allocation of every traversal loop there (10 % on frames that never take the beam).
@@ -1125,9 +1151,9 @@ __device__ __noinline__ int beam_collect(const float4* bvh4, int n_prims, float 
     if (lm == 0ull) return 0;
     const int lane = threadIdx.x & 63;
     // reciprocal-direction interval of the live lanes per axis
-    const float ilx = wave_min_f(live ? ix : INFINITY), ihx = wave_max_f(live ? ix : -INFINITY);
-    const float ily = wave_min_f(live ? iy : INFINITY), ihy = wave_max_f(live ? iy : -INFINITY);
-    const float ilz = wave_min_f(live ? iz : INFINITY), ihz = wave_max_f(live ? iz : -INFINITY);
+    float ilx = live ? ix : INFINITY, ihx = live ? ix : -INFINITY, ily = live ? iy : INFINITY, ihy = live ? iy : -INFINITY,
+          ilz = live ? iz : INFINITY, ihz = live ? iz : -INFINITY;
+    wave_minmax3(ilx, ihx, ily, ihy, ilz, ihz);
     // nothing beyond the farthest limit of a lane (its range, its "nearer than" bound, a hit it has) matters
     const float far = wave_max_f(live ? lim : 0.f);
     // origin interval: one point for camera rays, the lanes' hit points for occlusion rays
@@ -1136,9 +1162,9 @@ __device__ __noinline__ int beam_collect(const float4* bvh4, int n_prims, float 
         const int src = __ffsll((long long)lm) - 1;
         olx = ohx = __shfl(o_x, src, 64); oly = ohy = __shfl(o_y, src, 64); olz = ohz = __shfl(o_z, src, 64);
     } else {
-        olx = wave_min_f(live ? o_x : INFINITY); ohx = wave_max_f(live ? o_x : -INFINITY);
-        oly = wave_min_f(live ? o_y : INFINITY); ohy = wave_max_f(live ? o_y : -INFINITY);
-        olz = wave_min_f(live ? o_z : INFINITY); ohz = wave_max_f(live ? o_z : -INFINITY);
+        olx = live ? o_x : INFINITY; ohx = live ? o_x : -INFINITY; oly = live ? o_y : INFINITY; ohy = live ? o_y : -INFINITY;
+        olz = live ? o_z : INFINITY; ohz = live ? o_z : -INFINITY;
+        wave_minmax3(olx, ohx, oly, ohy, olz, ohz);
     }
     // an axis constrains when all reciprocals are finite and of one sign
     const bool px = ilx > 0.f, nx = ihx < 0.f, cx = (px || nx) && fabsf(ilx) < 1e37f && fabsf(ihx) < 1e37f;
